@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def models_dir():
+    return os.path.join(ROOT, "models") + "/"
+
+
+@pytest.fixture(scope="session")
+def oracle_scene(models_dir):
+    import oracle_lib as O
+    return O.Scene.load(models_dir, "Tor.obj")

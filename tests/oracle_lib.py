@@ -1,0 +1,166 @@
+"""ctypes binding of the CPU oracle (oracle/pt_oracle.c).
+
+Test infrastructure only: imported by tests/, by __graft_entry__.smoke() and by the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libpt_oracle.so")
+
+RNG_SEQUENTIAL, RNG_COUNTER = 0, 1
+TRIG_LIBM, TRIG_PORTABLE = 0, 1
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
+                ("pass_begin", C.c_int), ("pass_count", C.c_int), ("max_ray_reflections", C.c_int),
+                ("eps", C.c_float), ("error", C.c_float), ("seed", C.c_uint32),
+                ("rng_policy", C.c_int), ("trig_policy", C.c_int), ("threads", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples_traced", C.c_uint64), ("segments", C.c_uint64), ("contributing", C.c_uint64),
+                ("stage_exit", C.c_uint64 * 5), ("misses", C.c_uint64)]
+
+
+def build(force=False):
+    src = os.path.join(ORACLE_DIR, "pt_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
+        L.orc_scene_load.restype = vp
+        L.orc_scene_load.argtypes = [C.c_char_p, C.c_char_p]
+        L.orc_scene_from_arrays.restype = vp
+        L.orc_scene_from_arrays.argtypes = [fp, ip, C.c_int, fp, C.c_int]
+        L.orc_scene_free.argtypes = [vp]
+        L.orc_scene_num_triangles.argtypes = [vp]
+        L.orc_scene_num_materials.argtypes = [vp]
+        L.orc_scene_get_triangles.argtypes = [vp, fp, ip]
+        L.orc_scene_get_materials.argtypes = [vp, fp]
+        L.orc_render.argtypes = [vp, C.POINTER(Params), fp, fp, ip, C.POINTER(Stats)]
+        L.orc_resolve.argtypes = [C.c_int, C.c_int, fp, fp, ip, C.c_float, C.POINTER(C.c_ubyte), fp]
+        L.orc_write_bmp.restype = C.c_size_t
+        L.orc_write_bmp.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
+        L.orc_closest_hit.argtypes = [vp, fp, fp, C.c_float, fp]
+        L.orc_probe_minstd.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32), fp, C.POINTER(C.c_double)]
+        L.orc_probe_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_probe_unit_float.restype = C.c_float
+        L.orc_probe_unit_float.argtypes = [C.c_uint32]
+        L.orc_probe_jitter.restype = C.c_double
+        L.orc_probe_jitter.argtypes = [C.c_uint32]
+        L.orc_probe_sincos.argtypes = [fp, C.c_int, C.c_int, fp, fp]
+        L.orc_probe_intersect.argtypes = [vp, C.c_int, fp, fp, C.c_float, C.c_float, fp]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class Scene:
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("oracle: scene could not be loaded")
+        self.h = handle
+
+    @classmethod
+    def load(cls, model_dir, model_name):
+        if not model_dir.endswith("/"):
+            model_dir += "/"
+        return cls(lib().orc_scene_load(model_dir.encode(), model_name.encode()))
+
+    @classmethod
+    def from_arrays(cls, tri14, tri_mat, mats10):
+        tri14 = np.ascontiguousarray(tri14, np.float32).reshape(-1, 14)
+        tri_mat = np.ascontiguousarray(tri_mat, np.int32)
+        mats10 = np.ascontiguousarray(mats10, np.float32).reshape(-1, 10)
+        return cls(lib().orc_scene_from_arrays(_fp(tri14), _ip(tri_mat), len(tri14), _fp(mats10), len(mats10)))
+
+    @property
+    def n_tri(self):
+        return lib().orc_scene_num_triangles(self.h)
+
+    @property
+    def n_mat(self):
+        return lib().orc_scene_num_materials(self.h)
+
+    def triangles(self):
+        t = np.zeros((self.n_tri, 14), np.float32)
+        m = np.zeros(self.n_tri, np.int32)
+        lib().orc_scene_get_triangles(self.h, _fp(t), _ip(m))
+        return t, m
+
+    def materials(self):
+        a = np.zeros((self.n_mat, 10), np.float32)
+        lib().orc_scene_get_materials(self.h, _fp(a))
+        return a
+
+    def closest_hit(self, o, d, eps=1e-4):
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        t = C.c_float()
+        i = lib().orc_closest_hit(self.h, _fp(o), _fp(d), eps, C.byref(t))
+        return i, t.value
+
+    def __del__(self):
+        try:
+            lib().orc_scene_free(self.h)
+        except Exception:
+            pass
+
+
+def render(scene, width, height, spp, mrr, *, eps=1e-4, error=-1.0, seed=42, rng=RNG_COUNTER, trig=TRIG_PORTABLE,
+           rows=None, pass_begin=0, threads=0, accum=None):
+    r0, r1 = rows if rows is not None else (0, height)
+    n = (r1 - r0) * width
+    if accum is None:
+        s, s2, c = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+    else:
+        s, s2, c = accum
+    p = Params(width, height, r0, r1, pass_begin, spp, mrr, eps, error, seed, rng, trig, threads)
+    st = Stats()
+    rc = lib().orc_render(scene.h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"orc_render failed: {rc}")
+    stats = {"samples_traced": st.samples_traced, "segments": st.segments, "contributing": st.contributing,
+             "stage_exit": list(st.stage_exit), "misses": st.misses}
+    return s, s2, c, stats
+
+
+def resolve(width, height, s, s2, c, gamma=np.float32(1 / np.float32(2.2))):
+    bgr = np.zeros((height, width, 3), np.uint8)
+    disp = np.zeros(3, np.float32)
+    lib().orc_resolve(width, height, _fp(s), _fp(s2), _ip(c), C.c_float(gamma),
+                      bgr.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(disp))
+    return bgr, disp
+
+
+def write_bmp(path, bgr):
+    h, w, _ = bgr.shape
+    bgr = np.ascontiguousarray(bgr)
+    n = lib().orc_write_bmp(path.encode(), w, h, bgr.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    if n == 0:
+        raise RuntimeError("orc_write_bmp failed")
+    return n

@@ -1,0 +1,110 @@
+"""Pins the CPU oracle (oracle/pt_oracle.c) against every known answer available for the reference.
+
+The reference has no tests or fixtures of its own and cannot be built here (GLM is absent), so the anchors are
+the values SURVEY.md section 8(c) records for the reference (sequential RNG, THREADS_TO_RUN=1, seed 42), plus
+Random123's published Philox4x32-10 known-answer vectors for the counter RNG.
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+# (W, H, spp, MRR, error) -> (BMP md5, lit pixels or None, (max_disp, min_disp, aver_disp) as printed with %f)
+KNOWN = [
+    ((64, 64, 4, 3, 0.001), "994782793a83d584cb8f0815a5a65b90", None, (None, None, "0.986328")),
+    ((64, 64, 16, 8, -1.0), "7706ad2c812da31a0ad8efb1837dcf43", None, ("0.363144", None, "0.912172")),
+    ((64, 64, 16, 8, 0.001), "cf4dc5e658211d1116880c0405e6ecd8", None, (None, None, "0.908428")),
+    ((256, 256, 4, 3, 0.001), "ed4137839a531d82d4a6614ef3c12b13", 762, ("0.175574", "0.000000", "0.988375")),
+    ((256, 256, 4, 8, 0.001), "a1cf8513956da7501050772509aa14b2", None, ("0.641730", None, "0.973576")),
+]
+
+
+def test_minstd_rand0_draws():
+    raw = (C.c_uint32 * 4)()
+    unit = (C.c_float * 4)()
+    jit = (C.c_double * 4)()
+    O.lib().orc_probe_minstd(42, 4, raw, unit, jit)
+    assert list(raw) == [705894, 1126542223, 1579310009, 565444343]
+    expect = np.array([0.000328707043, 0.524587095, 0.735423505, 0.263305545], np.float32)
+    assert np.array_equal(np.array(list(unit), np.float32), expect)
+    assert jit[0] == 0.024587101791753829
+    assert jit[1] == -0.23669445921572174
+
+
+def test_philox4x32_10_random123_kat():
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    for ctr, key, want in kat:
+        out = (C.c_uint32 * 4)()
+        O.lib().orc_probe_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        assert tuple(out) == want
+
+
+def test_unit_float_and_jitter_ranges():
+    L = O.lib()
+    assert L.orc_probe_unit_float(0) == np.float32(2.0 ** -24)
+    assert L.orc_probe_unit_float(0xFFFFFFFF) == np.float32(1 - 2.0 ** -24)
+    assert 0 < L.orc_probe_unit_float(0x1FF) < 1e-7
+    assert L.orc_probe_jitter(0) == 2.0 ** -33 - 0.5
+    assert L.orc_probe_jitter(0xFFFFFFFF) == 0.5 - 2.0 ** -33
+
+
+def test_loader_counts(oracle_scene):
+    assert oracle_scene.n_tri == 270 and oracle_scene.n_mat == 5
+    tri, mat = oracle_scene.triangles()
+    assert (mat[:256] == 4).all()
+    assert list(mat[256:]) == [2, 2, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 3, 3]
+    mats = oracle_scene.materials()
+    assert np.allclose(mats[0, 3:6], 2.0) and np.allclose(mats[1:, 3:6], 0.0)
+    assert np.allclose(mats[:, 9], 96.078431)
+    # plane normals are unit length and the plane passes through vertex 0 (triangles.h:40-44)
+    n = tri[:, 0:3]
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
+    assert np.allclose((n * tri[:, 4:7]).sum(1) + tri[:, 3], 0.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("cfg,md5,lit,disp", KNOWN, ids=[str(k[0]) for k in KNOWN])
+def test_reference_frames_bit_exact(oracle_scene, tmp_path, cfg, md5, lit, disp):
+    W, H, spp, mrr, err = cfg
+    s, s2, c, _ = O.render(oracle_scene, W, H, spp, mrr, error=err, rng=O.RNG_SEQUENTIAL, trig=O.TRIG_LIBM)
+    bgr, d = O.resolve(W, H, s, s2, c)
+    path = str(tmp_path / "o.bmp")
+    n = O.write_bmp(path, bgr)
+    assert n == 54 + ((3 * W + 3) & ~3) * H
+    assert hashlib.md5(open(path, "rb").read()).hexdigest() == md5
+    if lit is not None:
+        assert int((c > 0).sum()) == lit
+    for got, want in zip(d, disp):
+        if want is not None:
+            assert "%f" % got == want
+
+
+def test_portable_sincos_tracks_libm():
+    rng = np.random.default_rng(1)
+    a = (rng.random(2_000_000, dtype=np.float32) * np.float32(6.283186)).astype(np.float32)
+    a[:4] = [0.0, 6.283186, 1.5707964, 3.1415927]
+    out = {}
+    for pol in (O.TRIG_LIBM, O.TRIG_PORTABLE):
+        s = np.zeros_like(a)
+        c = np.zeros_like(a)
+        O.lib().orc_probe_sincos(a.ctypes.data_as(C.POINTER(C.c_float)), len(a), pol,
+                                 s.ctypes.data_as(C.POINTER(C.c_float)), c.ctypes.data_as(C.POINTER(C.c_float)))
+        out[pol] = (s, c)
+    for k in (0, 1):
+        lm, pt = out[O.TRIG_LIBM][k], out[O.TRIG_PORTABLE][k]
+        ref = (np.sin if k == 0 else np.cos)(a.astype(np.float64))
+        # the portable form is within half an ulp (+ double rounding) of the true value ...
+        assert np.max(np.abs(pt.astype(np.float64) - ref) / np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)) < 0.501
+        # ... and differs from libm (whose sinf/cosf are faithfully, not correctly, rounded) in a few
+        # results per hundred, never by more than one ulp
+        diff = lm != pt
+        assert diff.mean() < 0.03
+        ulp = np.spacing(np.maximum(np.abs(lm[diff]), np.abs(pt[diff])))
+        assert np.all(np.abs(lm[diff] - pt[diff]) <= ulp)
