@@ -1,0 +1,125 @@
+/*
+ * pt_hip.h -- C ABI of the MI355X radiance integrator (libpt_hip.so).
+ *
+ * The reference (Andareon/Path-Tracing) has no plugin/FFI interface; the seam this library cuts is the
+ * pass loop of main() (main.cpp:110-160) expressed through the only object interface the reference has:
+ *
+ *   reference                                                     this ABI
+ *   ------------------------------------------------------------  ---------------------------------------
+ *   Scene::Scene(color_map&, color2_map&, samples_count&)          pt_scene_create / pt_scene_load_obj
+ *     scene.h:17-18, scene.cpp:16-23                                 (accumulators are per-call arguments)
+ *   void Scene::LoadModel(std::string)   scene.h:19, scene.cpp:26   pt_scene_load_obj
+ *   Ray(begin,dir,depth,coords) + while(ray.IsValid())              pt_render_device / pt_render_host
+ *     scene.TraceRay(ray)   main.cpp:116-140, scene.h:23, ray.h:21    (all passes x pixels x segments on the GPU)
+ *   dispersion stats + tonemap + set_pixel   main.cpp:162-201       pt_resolve
+ *   bitmap_image::save_image   bitmap_image.hpp:431-478             pt_write_bmp
+ *   Config fields read by the path   config.h:16-29                 pt_render_params
+ *
+ * Conventions: plain C types only, caller owns every buffer it passes, every function returns a pt_status
+ * (0 = ok) and never throws or exits; pt_last_error() returns the message of the calling thread's last failure.
+ * Accumulators are row-major, pixel p = (y - row_begin) * width + x:
+ *   sum  [3*p + c]  = sum of contributions        (color_map,     main.cpp:94)
+ *   sum2 [3*p + c]  = sum of squared contributions (color2_map,    main.cpp:96)
+ *   count[p]        = number of contributing paths (samples_count, main.cpp:98)
+ * (the reference's [x][y] nesting is an artefact of vector<vector<>>, not a format).
+ * A render call ADDS passes [pass_begin, pass_begin+pass_count) to the buffers it is given, so a frame can be
+ * rendered in slices (previews, time limits: main.cpp:111-114,141-158) and an image in row bands (multi-GPU).
+ * There is no CPU fallback: without a usable HIP device the render entry points fail with PT_ERR_NO_DEVICE.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = 1,
+    PT_ERR_IO = 2,             /* scene.cpp:32-35: the reference prints and exit(1)s */
+    PT_ERR_PARSE = 3,          /* malformed OBJ/MTL: undefined behaviour in the reference */
+    PT_ERR_NO_DEVICE = 4,
+    PT_ERR_HIP = 5,
+    PT_ERR_OUT_OF_MEMORY = 6
+} pt_status;
+
+typedef struct pt_scene pt_scene;   /* immutable after creation */
+
+/* One triangle as the reference stores it (triangles.h:19-25): plane_[4], vertices_[3][3], square. */
+#define PT_TRIANGLE_FLOATS 14
+/* One material as parsed from the MTL (material.h:22-28): Kd[3], Ke[3], Ks[3], Ns. */
+#define PT_MATERIAL_FLOATS 10
+
+typedef struct pt_render_params {
+    int32_t width, height;          /* --W / --H       config.h:16-17 */
+    int32_t row_begin, row_end;     /* rows [row_begin,row_end) of the image are rendered; buffers hold only them */
+    int32_t pass_begin, pass_count; /* passes (samples per pixel) to add: main.cpp:110 */
+    int32_t max_ray_reflections;    /* -MRR            config.h:19 (maximum number of path SEGMENTS) */
+    float eps;                      /* -EPS            config.h:22 */
+    float error;                    /* -ERR            config.h:23 (adaptive sampling threshold; <0 disables) */
+    uint32_t seed;                  /* -SEED           config.h:10 */
+} pt_render_params;
+
+typedef struct pt_render_stats {
+    uint64_t samples_traced;        /* primary rays generated (adaptive skips excluded) */
+    uint64_t segments;              /* Scene::TraceRay equivalents */
+    uint64_t contributing;          /* samples that reached an emitter */
+    uint64_t exact_tests;           /* ray-triangle pairs that needed the reference's full arithmetic */
+    uint64_t misses;                /* segments that found no triangle */
+    float kernel_ms;                /* HIP-event time of the integrator kernel on the launch stream; <0 if not timed */
+    int32_t n_triangles;
+} pt_render_stats;
+
+/* ---- scene ---------------------------------------------------------------------------------------- */
+
+/* Parse an OBJ + its MTL with the reference's token-stream semantics (Scene::LoadModel, scene.cpp:26-109) and
+ * upload the tables to `device` (HIP ordinal).  device < 0 builds a host-only scene (inspection, no rendering).
+ * model_dir is Config::model_path (used as a prefix, e.g. "../models/"), model_name is Config::model_name. */
+int pt_scene_load_obj(const char *model_dir, const char *model_name, int device, pt_scene **out);
+
+/* Build a scene from already-prepared tables (same layout pt_scene_get_triangles returns). */
+int pt_scene_create(const float *triangles, const int32_t *triangle_material, int32_t n_triangles,
+                    const float *materials, int32_t n_materials, int device, pt_scene **out);
+
+int pt_scene_counts(const pt_scene *scene, int32_t *n_triangles, int32_t *n_materials);
+int pt_scene_get_triangles(const pt_scene *scene, float *triangles, int32_t *triangle_material);
+int pt_scene_get_materials(const pt_scene *scene, float *materials);
+void pt_scene_destroy(pt_scene *scene);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+
+/* d_sum/d_sum2/d_count are DEVICE pointers on the scene's device, sized for the row band.  The kernel is
+ * enqueued on `hip_stream` (a hipStream_t, NULL = the default stream) and the call returns without
+ * synchronising unless `stats` is non-NULL (then it waits for the kernel and fills `stats`). */
+int pt_render_device(pt_scene *scene, const pt_render_params *params, float *d_sum, float *d_sum2,
+                     int32_t *d_count, void *hip_stream, pt_render_stats *stats);
+
+/* Same, with HOST buffers: uploads them, renders, downloads (PCIe-inclusive convenience path). */
+int pt_render_host(pt_scene *scene, const pt_render_params *params, float *sum, float *sum2, int32_t *count,
+                   pt_render_stats *stats);
+
+/* ---- resolve + image output (host side, as in the reference) --------------------------------------- */
+
+/* main.cpp:162-201: per-pixel mean, gamma tonemap *255, float->uint8 truncation (bitmap_image.hpp:194-206),
+ * dispersion statistics.  bgr: height*width*3 bytes, top-down rows, B,G,R order; pixels without samples stay 0.
+ * dispersion[0..2] = max, min, average exactly as they are embedded in the reference's output file name. */
+int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count,
+               float gamma, uint8_t *bgr, float *dispersion);
+
+/* bitmap_image::save_image (bitmap_image.hpp:431-478): 54-byte header, bottom-up rows padded to 4 bytes. */
+int pt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t *bgr);
+
+/* ---- misc ------------------------------------------------------------------------------------------- */
+int pt_abi_version(void);
+int pt_device_count(void);
+const char *pt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

@@ -1,0 +1,190 @@
+"""MI355X radiance integrator: thin ctypes binding of libpt_hip.so (include/pt_hip.h).
+
+The product is the C ABI; this module only loads it for the Python-side harnesses (tests, bench.py, smoke).
+There is no CPU fallback: if the shared library is missing, or no HIP device is usable, calls raise.
+
+The directory name contains a hyphen, so import it with
+    importlib.import_module("path-tracing_amd")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
+
+PT_OK = 0
+STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT_ERR_PARSE", 4: "PT_ERR_NO_DEVICE",
+                5: "PT_ERR_HIP", 6: "PT_ERR_OUT_OF_MEMORY"}
+
+# every symbol include/pt_hip.h declares
+ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
+               "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_resolve",
+               "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
+                ("pass_begin", C.c_int32), ("pass_count", C.c_int32), ("max_ray_reflections", C.c_int32),
+                ("eps", C.c_float), ("error", C.c_float), ("seed", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("samples_traced", C.c_uint64), ("segments", C.c_uint64), ("contributing", C.c_uint64),
+                ("exact_tests", C.c_uint64), ("misses", C.c_uint64), ("kernel_ms", C.c_float),
+                ("n_triangles", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile libpt_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC_DIR, "clean", "-s"])
+    subprocess.check_call(["make", "-C", CSRC_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run `make -C {CSRC_DIR}` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
+        L.pt_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.pt_scene_create.argtypes = [fp, ip, C.c_int32, fp, C.c_int32, C.c_int, C.POINTER(vp)]
+        L.pt_scene_counts.argtypes = [vp, ip, ip]
+        L.pt_scene_get_triangles.argtypes = [vp, fp, ip]
+        L.pt_scene_get_materials.argtypes = [vp, fp]
+        L.pt_scene_destroy.argtypes = [vp]
+        L.pt_scene_destroy.restype = None
+        L.pt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, C.POINTER(RenderStats)]
+        L.pt_render_host.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.POINTER(RenderStats)]
+        L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
+        L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
+        L.pt_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != PT_OK:
+        raise PtError(status, lib().pt_last_error().decode(errors="replace"))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def device_count():
+    return lib().pt_device_count()
+
+
+class Scene:
+    """Owns a pt_scene handle (Scene + LoadModel of the reference, scene.h:17-19)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load_obj(cls, model_dir, model_name, device=0):
+        h = C.c_void_p()
+        _check(lib().pt_scene_load_obj(model_dir.encode(), model_name.encode(), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def create(cls, triangles, triangle_material, materials, device=0):
+        t = np.ascontiguousarray(triangles, np.float32).reshape(-1, 14)
+        m = np.ascontiguousarray(triangle_material, np.int32)
+        k = np.ascontiguousarray(materials, np.float32).reshape(-1, 10)
+        h = C.c_void_p()
+        _check(lib().pt_scene_create(_fp(t), _ip(m), len(t), _fp(k), len(k), device, C.byref(h)))
+        return cls(h)
+
+    def counts(self):
+        nt, nm = C.c_int32(), C.c_int32()
+        _check(lib().pt_scene_counts(self._h, C.byref(nt), C.byref(nm)))
+        return nt.value, nm.value
+
+    def triangles(self):
+        nt, _ = self.counts()
+        t = np.zeros((nt, 14), np.float32)
+        m = np.zeros(nt, np.int32)
+        _check(lib().pt_scene_get_triangles(self._h, _fp(t), _ip(m)))
+        return t, m
+
+    def materials(self):
+        _, nm = self.counts()
+        k = np.zeros((nm, 10), np.float32)
+        _check(lib().pt_scene_get_materials(self._h, _fp(k)))
+        return k
+
+    def render_host(self, width, height, spp, mrr, *, eps=1e-4, error=-1.0, seed=42, rows=None, pass_begin=0,
+                    accum=None, want_stats=True):
+        r0, r1 = rows if rows is not None else (0, height)
+        n = (r1 - r0) * width
+        if accum is None:
+            s, s2, c = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        else:
+            s, s2, c = accum
+        p = RenderParams(width, height, r0, r1, pass_begin, spp, mrr, eps, error, seed)
+        st = RenderStats()
+        _check(lib().pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None))
+        return s, s2, c, st.as_dict()
+
+    def render_device(self, params, d_sum, d_sum2, d_count, stream=None, want_stats=False):
+        """d_* are raw device pointers (ints), e.g. torch tensors' data_ptr(); stream is a hipStream_t value."""
+        st = RenderStats()
+        _check(lib().pt_render_device(self._h, C.byref(params), C.c_void_p(d_sum), C.c_void_p(d_sum2),
+                                      C.c_void_p(d_count), C.c_void_p(stream or 0),
+                                      C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+    def close(self):
+        if self._h:
+            lib().pt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resolve(width, height, s, s2, c, gamma=None):
+    """main.cpp:162-201: returns (bgr uint8 [H,W,3], dispersion float32[3] = max, min, average)."""
+    if gamma is None:
+        gamma = np.float32(1) / np.float32(2.2)   # config.h:25
+    bgr = np.zeros((height, width, 3), np.uint8)
+    disp = np.zeros(3, np.float32)
+    s = np.ascontiguousarray(s, np.float32)
+    s2 = np.ascontiguousarray(s2, np.float32)
+    c = np.ascontiguousarray(c, np.int32)
+    _check(lib().pt_resolve(width, height, _fp(s), _fp(s2), _ip(c), C.c_float(gamma),
+                            bgr.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(disp)))
+    return bgr, disp
+
+
+def write_bmp(path, bgr):
+    h, w, _ = bgr.shape
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    _check(lib().pt_write_bmp(path.encode(), w, h, bgr.ctypes.data_as(C.POINTER(C.c_uint8))))

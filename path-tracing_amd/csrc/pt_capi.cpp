@@ -1,0 +1,323 @@
+// C ABI of libpt_hip.so (include/pt_hip.h).  Host side only: owns the device copies of the scene tables, maps HIP
+// errors to status codes, and implements the reference's host-side resolve and BMP writer.
+#include "../../include/pt_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pt_kernels.hpp"
+#include "pt_scene.hpp"
+
+struct pt_scene {
+    pt::HostScene host;
+    pt::DeviceTables tables;
+    int device = -1;
+    pt::CullRec *d_cull = nullptr;
+    pt::ExactRec *d_exact = nullptr;
+    pt::MatRec *d_mats = nullptr;
+    unsigned long long *d_stats = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    const int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+                         ? PT_ERR_NO_DEVICE
+                         : (e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP);
+    return fail(code, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define PT_HIP_TRY(expr)                                  \
+    do {                                                  \
+        hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+int upload(pt_scene *s, int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PT_ERR_NO_DEVICE, "no HIP device is visible: the integrator has no CPU fallback");
+    if (device >= n) return fail(PT_ERR_NO_DEVICE, "device ordinal " + std::to_string(device) + " out of range");
+    s->device = device;
+    PT_HIP_TRY(hipSetDevice(device));
+    const auto &t = s->tables;
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_cull), t.cull.size() * sizeof(pt::CullRec) + 64));
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_exact), t.exact.size() * sizeof(pt::ExactRec) + 64));
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_mats), t.mats.size() * sizeof(pt::MatRec) + 64));
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 8 * sizeof(unsigned long long)));
+    if (!t.cull.empty()) PT_HIP_TRY(hipMemcpy(s->d_cull, t.cull.data(), t.cull.size() * sizeof(pt::CullRec), hipMemcpyHostToDevice));
+    if (!t.exact.empty()) PT_HIP_TRY(hipMemcpy(s->d_exact, t.exact.data(), t.exact.size() * sizeof(pt::ExactRec), hipMemcpyHostToDevice));
+    if (!t.mats.empty()) PT_HIP_TRY(hipMemcpy(s->d_mats, t.mats.data(), t.mats.size() * sizeof(pt::MatRec), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipEventCreate(&s->ev0));
+    PT_HIP_TRY(hipEventCreate(&s->ev1));
+    return PT_OK;
+}
+
+int finish_scene(pt_scene *s, int device, pt_scene **out) {
+    for (int m : s->host.tri_mat)
+        if (m < 0 || m >= s->host.n_mat()) {
+            delete s;
+            return fail(PT_ERR_INVALID_ARGUMENT, "triangle refers to material " + std::to_string(m));
+        }
+    pt::build_device_tables(s->host, s->tables);
+    if (device >= 0) {
+        const int rc = upload(s, device);
+        if (rc != PT_OK) {
+            pt_scene_destroy(s);
+            return rc;
+        }
+    }
+    *out = s;
+    return PT_OK;
+}
+
+int check_params(const pt_scene *scene, const pt_render_params *p) {
+    if (!scene || !p) return fail(PT_ERR_INVALID_ARGUMENT, "null scene or params");
+    if (scene->device < 0) return fail(PT_ERR_NO_DEVICE, "scene was created without a device (device < 0)");
+    if (p->width <= 0 || p->height <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "width and height must be positive");
+    if (p->row_begin < 0 || p->row_end > p->height || p->row_begin > p->row_end)
+        return fail(PT_ERR_INVALID_ARGUMENT, "row band outside the image");
+    if (p->pass_begin < 0 || p->pass_count < 0) return fail(PT_ERR_INVALID_ARGUMENT, "negative pass range");
+    if (static_cast<long long>(p->width) * p->height > 0x7fffffffLL)
+        return fail(PT_ERR_INVALID_ARGUMENT, "image has more than 2^31 pixels");
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+int pt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *pt_last_error(void) { return g_error.c_str(); }
+
+int pt_scene_load_obj(const char *model_dir, const char *model_name, int device, pt_scene **out) {
+    if (!model_dir || !model_name || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    pt_scene *s = new (std::nothrow) pt_scene;
+    if (!s) return fail(PT_ERR_OUT_OF_MEMORY, "out of host memory");
+    std::string err;
+    bool io = false;
+    if (!pt::load_obj(model_dir, model_name, s->host, err, io)) {
+        delete s;
+        return fail(io ? PT_ERR_IO : PT_ERR_PARSE, err);
+    }
+    return finish_scene(s, device, out);
+}
+
+int pt_scene_create(const float *triangles, const int32_t *triangle_material, int32_t n_triangles, const float *materials,
+                    int32_t n_materials, int device, pt_scene **out) {
+    if (!out || n_triangles < 0 || n_materials < 0 || (n_triangles > 0 && (!triangles || !triangle_material)) ||
+        (n_materials > 0 && !materials))
+        return fail(PT_ERR_INVALID_ARGUMENT, "null table or negative count");
+    *out = nullptr;
+    pt_scene *s = new (std::nothrow) pt_scene;
+    if (!s) return fail(PT_ERR_OUT_OF_MEMORY, "out of host memory");
+    s->host.tri.assign(triangles, triangles + static_cast<size_t>(n_triangles) * PT_TRIANGLE_FLOATS);
+    s->host.tri_mat.assign(triangle_material, triangle_material + n_triangles);
+    s->host.mat.assign(materials, materials + static_cast<size_t>(n_materials) * PT_MATERIAL_FLOATS);
+    return finish_scene(s, device, out);
+}
+
+int pt_scene_counts(const pt_scene *scene, int32_t *n_triangles, int32_t *n_materials) {
+    if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
+    if (n_triangles) *n_triangles = scene->host.n_tri();
+    if (n_materials) *n_materials = scene->host.n_mat();
+    return PT_OK;
+}
+
+int pt_scene_get_triangles(const pt_scene *scene, float *triangles, int32_t *triangle_material) {
+    if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
+    if (triangles) std::memcpy(triangles, scene->host.tri.data(), scene->host.tri.size() * sizeof(float));
+    if (triangle_material) std::memcpy(triangle_material, scene->host.tri_mat.data(), scene->host.tri_mat.size() * sizeof(int32_t));
+    return PT_OK;
+}
+
+int pt_scene_get_materials(const pt_scene *scene, float *materials) {
+    if (!scene || !materials) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    std::memcpy(materials, scene->host.mat.data(), scene->host.mat.size() * sizeof(float));
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene *s) {
+    if (!s) return;
+    if (s->device >= 0) {
+        (void)hipSetDevice(s->device);
+        if (s->d_cull) (void)hipFree(s->d_cull);
+        if (s->d_exact) (void)hipFree(s->d_exact);
+        if (s->d_mats) (void)hipFree(s->d_mats);
+        if (s->d_stats) (void)hipFree(s->d_stats);
+        if (s->ev0) (void)hipEventDestroy(s->ev0);
+        if (s->ev1) (void)hipEventDestroy(s->ev1);
+    }
+    delete s;
+}
+
+int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, float *d_sum2, int32_t *d_count,
+                     void *hip_stream, pt_render_stats *stats) {
+    const int rc = check_params(scene, p);
+    if (rc != PT_OK) return rc;
+    if (!d_sum || !d_sum2 || !d_count) return fail(PT_ERR_INVALID_ARGUMENT, "null accumulator pointer");
+    PT_HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const pt::CullConstants cc = pt::cull_constants(scene->tables.geo, p->eps);
+    pt::RenderArgs a;
+    a.cull = scene->d_cull;
+    a.exact = scene->d_exact;
+    a.mats = scene->d_mats;
+    a.sum = d_sum;
+    a.sum2 = d_sum2;
+    a.count = d_count;
+    a.stats = stats ? scene->d_stats : nullptr;
+    a.n_chunks = static_cast<int32_t>(scene->tables.cull.size() / pt::kChunk);
+    a.n_tri = scene->host.n_tri();
+    a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+    a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
+    a.eps = p->eps; a.error = p->error; a.seed = p->seed;
+    a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
+    a.blocks_x = (p->width + 15) / 16;
+    if (stats) {
+        PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 8 * sizeof(unsigned long long), stream));
+        PT_HIP_TRY(hipEventRecord(scene->ev0, stream));
+    }
+    PT_HIP_TRY(pt::launch_integrator(a, stream));
+    if (stats) {
+        PT_HIP_TRY(hipEventRecord(scene->ev1, stream));
+        unsigned long long h[8];
+        PT_HIP_TRY(hipMemcpyAsync(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
+        PT_HIP_TRY(hipStreamSynchronize(stream));
+        float ms = -1.0f;
+        PT_HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+        stats->samples_traced = h[0];
+        stats->segments = h[1];
+        stats->contributing = h[2];
+        stats->exact_tests = h[3];
+        stats->misses = h[4];
+        stats->kernel_ms = ms;
+        stats->n_triangles = scene->host.n_tri();
+    }
+    return PT_OK;
+}
+
+int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float *sum2, int32_t *count,
+                   pt_render_stats *stats) {
+    const int rc = check_params(scene, p);
+    if (rc != PT_OK) return rc;
+    if (!sum || !sum2 || !count) return fail(PT_ERR_INVALID_ARGUMENT, "null accumulator pointer");
+    PT_HIP_TRY(hipSetDevice(scene->device));
+    const size_t n = static_cast<size_t>(p->row_end - p->row_begin) * p->width;
+    if (n == 0) return PT_OK;
+    float *d_sum = nullptr, *d_sum2 = nullptr;
+    int32_t *d_count = nullptr;
+    int result = PT_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_sum), n * 12);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_sum2), n * 12);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_count), n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_sum, sum, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_sum2, sum2, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_count, count, n * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) result = hip_fail(e, "staging the accumulators");
+    if (result == PT_OK) result = pt_render_device(scene, p, d_sum, d_sum2, d_count, nullptr, stats);
+    if (result == PT_OK) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(sum, d_sum, n * 12, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(sum2, d_sum2, n * 12, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(count, d_count, n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) result = hip_fail(e, "reading the accumulators back");
+    }
+    if (d_sum) (void)hipFree(d_sum);
+    if (d_sum2) (void)hipFree(d_sum2);
+    if (d_count) (void)hipFree(d_count);
+    return result;
+}
+
+int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
+               uint8_t *bgr, float *dispersion) {
+    if (width <= 0 || height <= 0 || !sum || !sum2 || !count || !bgr)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
+    float max_d = 0.0f, min_d = INFINITY, avg_d = 0.0f;
+    std::memset(bgr, 0, static_cast<size_t>(width) * height * 3);   // image.clear(), main.cpp:106
+    for (int y = 0; y < height; ++y) {
+        for (int x = 0; x < width; ++x) {
+            const size_t p = static_cast<size_t>(y) * width + x;
+            if (!count[p]) {   // main.cpp:165-168
+                avg_d += 1;
+                continue;
+            }
+            const float n = static_cast<float>(count[p]);
+            float d = 0.0f, c[3];
+            float dd[3];
+            for (int k = 0; k < 3; ++k) {
+                const float mean = sum[3 * p + k] / n;
+                dd[k] = sum2[3 * p + k] / n - mean * mean;
+                c[k] = std::pow(sum[3 * p + k] / n, gamma) * 255.0f;   // main.cpp:179-182
+            }
+            d = dd[0] + dd[1] + dd[2];
+            if (d > max_d) max_d = d;
+            if (d < min_d) min_d = d;
+            avg_d += d;
+            // set_pixel(x, y, float, float, float): float -> unsigned char (bitmap_image.hpp:194-206)
+            bgr[3 * p + 0] = static_cast<uint8_t>(static_cast<int>(c[2]));
+            bgr[3 * p + 1] = static_cast<uint8_t>(static_cast<int>(c[1]));
+            bgr[3 * p + 2] = static_cast<uint8_t>(static_cast<int>(c[0]));
+        }
+    }
+    avg_d /= width * height;
+    if (dispersion) {
+        dispersion[0] = max_d;
+        dispersion[1] = min_d;
+        dispersion[2] = avg_d;
+    }
+    return PT_OK;
+}
+
+int pt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t *bgr) {
+    if (!path || width <= 0 || height <= 0 || !bgr) return fail(PT_ERR_INVALID_ARGUMENT, "null argument or empty image");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(PT_ERR_IO, std::string("cannot open ") + path + " for writing");
+    const uint32_t row_bytes = static_cast<uint32_t>(width) * 3u;
+    const uint32_t size_image = ((row_bytes + 3u) & 0x0000FFFCu) * static_cast<uint32_t>(height);   // sic: 16-bit mask
+    uint8_t hdr[54];
+    std::memset(hdr, 0, sizeof hdr);
+    auto put32 = [&](int at, uint32_t v) { for (int i = 0; i < 4; ++i) hdr[at + i] = static_cast<uint8_t>(v >> (8 * i)); };
+    auto put16 = [&](int at, uint16_t v) { hdr[at] = static_cast<uint8_t>(v); hdr[at + 1] = static_cast<uint8_t>(v >> 8); };
+    put16(0, 19778);
+    put32(2, 54u + size_image);
+    put32(10, 54u);
+    put32(14, 40u);
+    put32(18, static_cast<uint32_t>(width));
+    put32(22, static_cast<uint32_t>(height));
+    put16(26, 1);
+    put16(28, 24);
+    put32(34, size_image);
+    bool ok = std::fwrite(hdr, 1, sizeof hdr, f) == sizeof hdr;
+    const uint32_t pad = (4u - row_bytes % 4u) % 4u;
+    const uint8_t zeros[4] = {0, 0, 0, 0};
+    for (int i = 0; ok && i < height; ++i) {
+        ok = std::fwrite(bgr + static_cast<size_t>(height - i - 1) * row_bytes, 1, row_bytes, f) == row_bytes;
+        if (ok && pad) ok = std::fwrite(zeros, 1, pad, f) == pad;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? PT_OK : fail(PT_ERR_IO, std::string("short write to ") + path);
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// Radiance-integrator kernel for gfx950 (MI355X).  One lane = one pixel's path, one wave = an 8x8 pixel tile,
+// all passes x segments x triangles of a row band in one launch.
+//
+// Per path segment a wave does three things:
+//   1. CULL   every triangle, wave-uniformly: the triangle's 12-float record comes in through scalar loads and is
+//             broadcast from SGPRs, the lanes' rays stay in VGPRs.  The test is a cheap CONSERVATIVE version of the
+//             reference's Triangle::Intersect (triangles.h:48-73): it may only say "cannot be a hit".  Survivors are
+//             recorded as one bit per triangle in per-lane mask words parked in LDS.
+//   2. EXACT  for the few survivors (about two per ray), each lane walks its own list in triangle order and runs the
+//             reference's arithmetic operation for operation (same association, no FMA contraction, IEEE divide and
+//             sqrt), so `t`, the hit decision and the closest-hit choice are bit-identical to the CPU path.
+//   3. SHADE  Material::Process + the three lobes (material.h:36-102), Ray::Reflect (ray.h:45-50), accumulators in
+//             registers (material.h:74-77), counter-based Philox4x32-10 randoms keyed by (seed | pixel, pass, segment).
+//
+// Everything that decides a result is plain IEEE binary32/binary64 arithmetic; only step 1 uses fused multiply-adds
+// and v_rcp_f32, and step 1 cannot change a result (DESIGN.md "Culling: why it cannot reject a hit").
+#include <hip/hip_runtime.h>
+
+#include "pt_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+namespace {
+
+constexpr int kBlock = 256;               // 4 waves, each an independent 8x8 pixel tile
+constexpr int kTileChunks = 16;           // mask words kept in LDS per lane between cull and exact (512 triangles)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0;
+        c1 = l1;
+        c2 = h0 ^ c3 ^ k1;
+        c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+__device__ __forceinline__ float unit_float(uint32_t w) {   // (0,1), never 0 or 1
+    return static_cast<float>(((w >> 9) << 1) | 1u) * 5.9604644775390625e-08f;
+}
+__device__ __forceinline__ double jitter_double(uint32_t w) {   // (-0.5,0.5)
+    return (static_cast<double>(w) + 0.5) * 2.3283064365386962890625e-10 - 0.5;
+}
+
+// sin/cos of a float angle in [0, 2pi]: double +,-,* only, so the result is the same on every IEEE machine.
+__device__ __forceinline__ void portable_sincos(float a, float &s_out, float &c_out) {
+    const double x = static_cast<double>(a);
+    const int k = static_cast<int>(x * 0.63661977236758138 + 0.5);
+    const double kd = static_cast<double>(k);
+    const double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04
+                    + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double sn = r + r * (z * ps);
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
+                    + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double cs = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int q = k & 3;
+    const double s = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
+    const double c = (q == 0) ? cs : (q == 1) ? -sn : (q == 2) ? -cs : sn;
+    s_out = static_cast<float>(s);
+    c_out = static_cast<float>(c);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1. CULL: may only answer "this triangle cannot be accepted by Triangle::Intersect for this ray".
+// ---------------------------------------------------------------------------------------------------------------
+struct Ray {
+    float ox, oy, oz, dx, dy, dz;
+};
+
+__device__ __forceinline__ bool cull_reject(const CullRec &r, const Ray &q, float k1, float k2, float a_max, float m0,
+                                            float t_guard) {
+    const float num = __builtin_fmaf(q.ox, r.n[0], __builtin_fmaf(q.oy, r.n[1], __builtin_fmaf(q.oz, r.n[2], r.w)));
+    const float den = __builtin_fmaf(q.dx, r.n[0], __builtin_fmaf(q.dy, r.n[1], q.dz * r.n[2]));
+    const float rden = __builtin_amdgcn_rcpf(den);
+    const float t = -num * rden;
+    const float px = __builtin_fmaf(t, q.dx, q.ox), py = __builtin_fmaf(t, q.dy, q.oy), pz = __builtin_fmaf(t, q.dz, q.oz);
+    const float u = __builtin_fmaf(px, r.au[0], __builtin_fmaf(py, r.au[1], __builtin_fmaf(pz, r.au[2], r.cu)));
+    const float v = __builtin_fmaf(px, r.av[0], __builtin_fmaf(py, r.av[1], __builtin_fmaf(pz, r.av[2], r.cv)));
+    const float w = (1.0f - u) - v;
+    const float e = __builtin_fminf(__builtin_fminf(u, v), w);
+    // |t - t_reference| <= et ; a point the reference accepts has every barycentric coordinate >= -mg
+    const float et = __builtin_fmaf(k1, __builtin_fabsf(t), k2) * __builtin_fabsf(rden);
+    const float mg = __builtin_fmaf(a_max, et, m0);
+    const bool outside = e < -mg;
+    const bool behind = t < -et;                           // then t_reference < 0 < eps (triangles.h:51)
+    const bool trusted = __builtin_fabsf(t) < t_guard;     // false for NaN/inf and for grazing rays
+    return trusted & (outside | behind);                   // bitwise on purpose: no divergent branches in the cull loop
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2. EXACT: Triangle::Intersect (triangles.h:48-73) with PlaneIntersect (:10-13) and ParallelogramSquare (:15-17).
+// Every operation is written in the reference's order; GLM's cross/length association is kept.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float area_of(float ax, float ay, float az, float bx, float by, float bz) {
+    const float cx = ay * bz - by * az;
+    const float cy = az * bx - bz * ax;
+    const float cz = ax * by - bx * ay;
+    return __builtin_sqrtf(cx * cx + cy * cy + cz * cz);
+}
+
+__device__ __forceinline__ bool exact_intersect(const ExactRec *__restrict__ rec, const Ray &q, float eps, float &best) {
+    const float4 r0 = reinterpret_cast<const float4 *>(rec)[0];   // plane
+    const float4 r1 = reinterpret_cast<const float4 *>(rec)[1];   // v0, square
+    const float4 r2 = reinterpret_cast<const float4 *>(rec)[2];   // v1, material
+    const float4 r3 = reinterpret_cast<const float4 *>(rec)[3];   // v2
+    const float signed_dist = q.dx * r0.x + q.dy * r0.y + q.dz * r0.z;
+    const float nd = -(q.ox * r0.x + q.oy * r0.y + q.oz * r0.z + r0.w) / signed_dist;
+    const bool stage_a = !(nd >= best || nd < eps);
+    const float px = q.ox + q.dx * nd, py = q.oy + q.dy * nd, pz = q.oz + q.dz * nd;
+    const float f0x = px - r1.x, f0y = py - r1.y, f0z = pz - r1.z;
+    const float f1x = px - r2.x, f1y = py - r2.y, f1z = pz - r2.z;
+    const float f2x = px - r3.x, f2y = py - r3.y, f2z = pz - r3.z;
+    const float sq = r1.w;
+    const float s1 = area_of(f0x, f0y, f0z, f1x, f1y, f1z);
+    const bool stage_b = !(s1 > sq + eps);
+    const float s2 = area_of(f0x, f0y, f0z, f2x, f2y, f2z);
+    const bool stage_c = !(s1 + s2 > sq + eps);
+    const float s3 = area_of(f2x, f2y, f2z, f1x, f1y, f1z);
+    const bool stage_d = !(__builtin_fabsf(sq - s1 - s2 - s3) > eps);
+    const bool hit = stage_a && stage_b && stage_c && stage_d;
+    if (hit) best = nd;
+    return hit;
+}
+
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // glm::normalize(vec4(x,y,z,0))
+    const float inv = 1.0f / __builtin_sqrtf((x * x + y * y) + z * z);
+    x = x * inv; y = y * inv; z = z * inv;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// The kernel
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
+    __shared__ uint32_t cand[kTileChunks][kBlock];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    // block = 16x16 pixels, wave = 8x8
+    const int bx = blockIdx.x % a.blocks_x, by = blockIdx.x / a.blocks_x;
+    const int x = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = a.row_begin + by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool in_image = x < a.width && y < a.row_end;
+    const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
+    const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
+
+    float sr = 0, sg = 0, sb = 0, qr = 0, qg = 0, qb = 0;
+    int cnt = 0;
+    if (in_image) {
+        sr = a.sum[3 * p]; sg = a.sum[3 * p + 1]; sb = a.sum[3 * p + 2];
+        qr = a.sum2[3 * p]; qg = a.sum2[3 * p + 1]; qb = a.sum2[3 * p + 2];
+        cnt = a.count[p];
+    }
+    uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_exact = 0, n_miss = 0;
+
+    const int mrr = a.mrr;
+    const float eps = a.eps;
+    // Cull margins live in VGPRs: a VALU instruction can name only one SGPR, so an SGPR-resident constant next to an
+    // SGPR-resident triangle coefficient would cost a v_mov per use.  The empty asm stops rematerialisation.
+    float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, t_guard = a.t_guard;
+    asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(t_guard));
+
+    for (int pass = a.pass_begin; pass < a.pass_begin + a.pass_count; ++pass) {
+        // Adaptive skip, main.cpp:118-125.
+        bool skip = !in_image;
+        {
+            const float sc = static_cast<float>(cnt);
+            if (pass > 10 && sc > 0) {
+                const float mr = sr / sc, mg_ = sg / sc, mb = sb / sc;
+                const float dr = qr / sc - mr * mr, dg = qg / sc - mg_ * mg_, db = qb / sc - mb * mb;
+                if ((pass % 4) && dr < a.error && dg < a.error && db < a.error) skip = true;
+            }
+        }
+        if (__all(skip)) continue;
+
+        // Primary ray, main.cpp:126-129 + Ray ctor ray.h:21-25 (double arithmetic, then narrowed).
+        Ray q;
+        float tr = 1.0f, tg = 1.0f, tb = 1.0f;   // Ray::color_ (throughput), ray.h:17
+        int depth = mrr;
+        if (!skip) {
+            uint32_t w0, w1, w2, w3;
+            philox4x32_10(gpix, static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
+            const double jx = jitter_double(w0), jy = jitter_double(w1);
+            q.dx = static_cast<float>((x + jx) / a.width - 0.5f);
+            q.dy = static_cast<float>(-(y + jy) / a.height + 0.5f);
+            q.dz = 1.0f;
+            const float inv = 1.0f / __builtin_sqrtf((q.dx * q.dx + q.dy * q.dy) + (1.0f * 1.0f + 0.0f * 0.0f));
+            q.dx = q.dx * inv; q.dy = q.dy * inv; q.dz = q.dz * inv;
+            q.ox = 0.0f; q.oy = 0.0f; q.oz = -20.0f;
+            depth = 0;
+            ++n_traced;
+        } else {
+            q.ox = q.oy = q.oz = 0.0f; q.dx = q.dy = 0.0f; q.dz = 1.0f;
+        }
+
+        for (;;) {
+            const bool valid = depth < mrr && (tr != 0.0f || tg != 0.0f || tb != 0.0f);   // Ray::IsValid, ray.h:52-54
+            if (!__any(valid)) break;
+
+            float best = __builtin_inff();
+            int hit = -1;
+            for (int tile0 = 0; tile0 < a.n_chunks; tile0 += kTileChunks) {
+                const int nch = min(kTileChunks, a.n_chunks - tile0);
+                // ---- 1. cull
+                for (int c = 0; c < nch; ++c) {
+                    const CullRec *__restrict__ recs = a.cull + static_cast<size_t>(tile0 + c) * kChunk;
+                    uint32_t m = 0;
+                    // Four triangles per straight-line block: 48 SGPRs of records in flight; a full unroll makes the
+                    // scheduler hoist all 32 scalar loads and spill hundreds of SGPRs.
+#pragma unroll 4
+                    for (int j = 0; j < kChunk; ++j) {
+                        const bool rej = cull_reject(recs[j], q, k1, k2, a_max, m0, t_guard);
+                        m |= rej ? 0u : (1u << j);
+                    }
+                    cand[c][tid] = valid ? m : 0u;
+                }
+                // ---- 2. exact, in triangle order (scene.cpp:116-120)
+                int c = -1;
+                uint32_t m = 0;
+                for (;;) {
+                    while (m == 0 && c + 1 < nch) {
+                        ++c;
+                        m = cand[c][tid];
+                    }
+                    if (!__any(m != 0)) break;
+                    if (m != 0) {
+                        const int j = __builtin_ctz(m);
+                        m &= m - 1;
+                        const int i = (tile0 + c) * kChunk + j;
+                        if (exact_intersect(a.exact + i, q, eps, best)) hit = i;
+                        ++n_exact;
+                    }
+                }
+            }
+
+            // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
+            if (valid) {
+                ++n_segments;
+                if (hit < 0) {
+                    ++n_miss;
+                    depth = mrr;   // MakeInvalid
+                } else {
+                    const ExactRec *__restrict__ rec = a.exact + hit;
+                    const float4 pl = reinterpret_cast<const float4 *>(rec)[0];
+                    const int mi = rec->material;
+                    const float px = q.ox + q.dx * best, py = q.oy + q.dy * best, pz = q.oz + q.dz * best;
+                    const float4 m0v = reinterpret_cast<const float4 *>(a.mats + mi)[0];   // kd, chance0
+                    const float4 m1v = reinterpret_cast<const float4 *>(a.mats + mi)[1];   // ks, chance1
+                    const int4 m2v = reinterpret_cast<const int4 *>(a.mats + mi)[2];       // n_lobes, kind0, kind1
+                    uint32_t w0, w1, w2, w3;
+                    philox4x32_10(gpix, static_cast<uint32_t>(pass), static_cast<uint32_t>(depth), 0u, a.seed, kPhiloxKey1,
+                                  w0, w1, w2, w3);
+                    int kind;
+                    if (m2v.x == 0) {
+                        kind = -1;
+                    } else if (m2v.x == 1) {
+                        kind = m2v.y;
+                    } else {
+                        // `while (sample > 0) { ++i; sample -= chance_[i]; }` with sample in (0,1); past the last lobe
+                        // the reference reads out of bounds, here the last lobe is kept.
+                        const float sample = unit_float(w0);
+                        kind = (sample - m0v.w > 0) ? m2v.z : m2v.y;
+                    }
+                    if (kind < 0) {
+                        depth = mrr;
+                    } else if (kind == 0) {   // emissive, material.h:68-79
+                        if (!((q.dx * pl.x + q.dy * pl.y) + q.dz * pl.z > 0)) {
+                            const float cr = tr * m0v.x, cg = tg * m0v.y, cb = tb * m0v.z;
+                            sr += cr; sg += cg; sb += cb;
+                            qr += cr * cr; qg += cg * cg; qb += cb * cb;
+                            ++cnt;
+                            ++n_contrib;
+                        }
+                        depth = mrr;
+                    } else if (kind == 1) {   // glossy, material.h:83-85
+                        const float dn = (pl.x * q.dx + pl.y * q.dy) + pl.z * q.dz;
+                        float rx = q.dx - pl.x * dn * 2.0f, ry = q.dy - pl.y * dn * 2.0f, rz = q.dz - pl.z * dn * 2.0f;
+                        normalize3(rx, ry, rz);
+                        q.ox = px + pl.x * eps; q.oy = py + pl.y * eps; q.oz = pz + pl.z * eps;
+                        q.dx = rx; q.dy = ry; q.dz = rz;
+                        tr *= m1v.x; tg *= m1v.y; tb *= m1v.z;
+                        ++depth;
+                    } else {   // diffuse, material.h:90-100
+                        const float xi1 = unit_float(w1), xi2 = unit_float(w2);
+                        const float ang = 2 * 3.141593f * xi2;
+                        float sn, cs;
+                        portable_sincos(ang, sn, cs);
+                        const float sq = __builtin_sqrtf(xi1);
+                        float rx = sq * cs, ry = sq * sn, rz = __builtin_sqrtf(1 - xi1);
+                        normalize3(rx, ry, rz);
+                        if ((pl.x * rx + pl.y * ry) + pl.z * rz < 0) { rx *= -1; ry *= -1; rz *= -1; }
+                        float dt = (pl.x * rx + pl.y * ry) + pl.z * rz;
+                        dt = dt > 0.0f ? dt : 0.0f;
+                        normalize3(rx, ry, rz);   // Ray::Reflect normalises again, ray.h:47
+                        q.ox = px + pl.x * eps; q.oy = py + pl.y * eps; q.oz = pz + pl.z * eps;
+                        q.dx = rx; q.dy = ry; q.dz = rz;
+                        tr *= m0v.x * dt; tg *= m0v.y * dt; tb *= m0v.z * dt;
+                        ++depth;
+                    }
+                }
+            }
+        }
+    }
+
+    if (in_image) {
+        a.sum[3 * p] = sr; a.sum[3 * p + 1] = sg; a.sum[3 * p + 2] = sb;
+        a.sum2[3 * p] = qr; a.sum2[3 * p + 1] = qg; a.sum2[3 * p + 2] = qb;
+        a.count[p] = cnt;
+    }
+    if (a.stats) {
+        atomicAdd(&a.stats[0], static_cast<unsigned long long>(n_traced));
+        atomicAdd(&a.stats[1], static_cast<unsigned long long>(n_segments));
+        atomicAdd(&a.stats[2], static_cast<unsigned long long>(n_contrib));
+        atomicAdd(&a.stats[3], static_cast<unsigned long long>(n_exact));
+        atomicAdd(&a.stats[4], static_cast<unsigned long long>(n_miss));
+    }
+}
+
+hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
+    const int rows = args.row_end - args.row_begin;
+    if (rows <= 0 || args.width <= 0) return hipSuccess;
+    const int blocks_y = (rows + 15) / 16;
+    const unsigned grid = static_cast<unsigned>(args.blocks_x) * static_cast<unsigned>(blocks_y);
+    hipLaunchKernelGGL(integrate_kernel, dim3(grid), dim3(kBlock), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace pt

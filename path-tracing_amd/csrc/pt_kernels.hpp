@@ -1,0 +1,31 @@
+// Launch interface of the integrator kernel (pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "pt_scene.hpp"
+
+namespace pt {
+
+constexpr uint32_t kPhiloxKey1 = 0x50544831u;   // "PTH1": second Philox key word (the first is the seed)
+
+struct RenderArgs {
+    const CullRec *cull;      // n_chunks * kChunk records
+    const ExactRec *exact;    // n_tri
+    const MatRec *mats;
+    float *sum, *sum2;        // row band, 3 floats per pixel
+    int32_t *count;
+    unsigned long long *stats;   // 5 counters or nullptr
+    int32_t n_chunks, n_tri;
+    int32_t width, height, row_begin, row_end;
+    int32_t pass_begin, pass_count, mrr;
+    float eps, error;
+    uint32_t seed;
+    float k1, k2, a_max, m0, t_guard;   // cull margins (pt_scene.hpp: CullConstants)
+    int32_t blocks_x;                   // ceil(width / 16)
+};
+
+hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);
+
+}  // namespace pt
