@@ -225,7 +225,10 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
                         const bool rej = cull_reject(recs[j], q, k1, k2, a_max, m0, t_guard);
                         m |= rej ? 0u : (1u << j);
                     }
-                    cand[c][tid] = valid ? m : 0u;
+                    // the last word is padded with records that are never looked at
+                    const int left = a.n_tri - (tile0 + c) * kChunk;
+                    const uint32_t live = left >= kChunk ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                    cand[c][tid] = valid ? (m & live) : 0u;
                 }
                 // ---- 2. exact, in triangle order (scene.cpp:116-120)
                 int c = -1;

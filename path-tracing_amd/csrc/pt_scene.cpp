@@ -210,11 +210,10 @@ void build_device_tables(const HostScene &s, DeviceTables &out) {
         }
         for (int k = 4; k < 13; ++k) out.geo.r_max = std::max(out.geo.r_max, static_cast<double>(std::fabs(r[k])));
     }
-    // Pad to whole mask words with records that are always culled: plane(P) = +huge, n.d = 0 -> t = -inf.
+    // Pad to whole mask words; the kernel masks the padding bits off, the records only have to be readable.
     while (out.cull.size() % kChunk) {
         CullRec c;
         std::memset(&c, 0, sizeof c);
-        c.w = 1.0e30f;
         out.cull.push_back(c);
     }
     out.mats.resize(s.n_mat());

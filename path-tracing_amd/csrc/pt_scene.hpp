@@ -60,7 +60,7 @@ struct CullGeometry {
 };
 
 struct DeviceTables {
-    std::vector<CullRec> cull;     // padded to a multiple of kChunk with never-candidate records
+    std::vector<CullRec> cull;     // padded with zero records to a multiple of kChunk
     std::vector<ExactRec> exact;   // n_tri
     std::vector<MatRec> mats;      // n_mat
     CullGeometry geo;
