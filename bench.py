@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the radiance-integrator hot path (BASELINE.json metric: Msamples/s = W*H*spp / wall on Tor.obj).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete frame: zero the accumulators, trace every sample of every pixel of this rank's row band
+(all passes x segments x triangles in one kernel launch through the C ABI), and -- for N > 1 -- the single RCCL
+gather of the accumulator bands to rank 0.  At N = 1 the frame is BASELINE.json configs[1]: models/Tor.obj,
+1920x1080, 64 spp, -MRR 8, adaptive sampling off (-ERR -1, so all W*H*spp samples are traced).  For N > 1 the image
+grows with N (1920 x 1080*N... see frame_for()) so that every GPU keeps a 1080p-sized band: weak scaling.
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
+  roofline      FP32 vector-ALU roofline of the integrator kernel (the path is neither HBM- nor
+                MFMA-bound), HIP-event kernel time measured live on the launch stream, plus the HBM view north_star asks for
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_TEST = 31.5          # reference's own average over its stage-exit mix
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+BASE_W, BASE_H, SPP, MRR = 1920, 1080, 64, 8
+
+
+def frame_for(n_gpus):
+    """Image whose row bands give every GPU 1920*1080 pixels (weak scaling).  N=4 is the 4K frame of configs[3]."""
+    if n_gpus % 4 == 0:
+        return BASE_W * 2, BASE_H * 2 * (n_gpus // 4)
+    return BASE_W, BASE_H * n_gpus
+
+
+def host_cores():
+    """CPU threads this process may really use: min(affinity, cgroup quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(models, target_seconds):
+    """Times the CPU oracle (kind "port") on a bounded sample of the same workload: the central rows of the
+    1920x1080 frame, -MRR 8, counter RNG, all host cores."""
+    import oracle_lib as O
+    sc = O.Scene.load(models, "Tor.obj")
+    cores = min(O.lib().orc_max_threads(), host_cores())
+    r0 = BASE_H // 2 - 8
+    t = time.perf_counter()
+    O.render(sc, BASE_W, BASE_H, 1, MRR, rows=(r0, r0 + 16), threads=cores)       # calibration: 30 720 samples
+    dt = max(time.perf_counter() - t, 1e-3)
+    rate = BASE_W * 16 / dt
+    rows = 120
+    spp = max(1, min(64, int(rate * target_seconds / (BASE_W * rows))))
+    r0 = BASE_H // 2 - rows // 2
+    t = time.perf_counter()
+    _, _, _, st = O.render(sc, BASE_W, BASE_H, spp, MRR, rows=(r0, r0 + rows), threads=cores)
+    dt = time.perf_counter() - t
+    n = BASE_W * rows * spp
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"Tor.obj 1920x1080 frame, rows {r0}-{r0 + rows} x {spp} spp, MRR {MRR} = {n} samples in {dt:.1f} s "
+                      f"({st['segments']} segments); oracle/pt_oracle.c, OpenMP over rows"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of the frame (BASELINE configs: 64 / 256 / 1024)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget; 0 skips it")
+    ap.add_argument("--write-bmp", default="", help="resolve rank 0's gathered frame and write it here")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    pt = importlib.import_module("path-tracing_amd")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU with torch.distributed.run")
+    if not torch.cuda.is_available() or pt.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the integrator has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H = frame_for(world)
+    rows = H // world
+    r0, r1 = rank * rows, (rank + 1) * rows
+    npx = rows * W
+    models = os.path.join(ROOT, "models") + "/"
+    scene = pt.Scene.load_obj(models, "Tor.obj", device=local)
+    n_tri = scene.counts()[0]
+
+    # one contiguous band buffer: sum[3n] | sum2[3n] | count[n] (int32 bits) -> a single gather moves everything
+    band = torch.zeros(7 * npx, dtype=torch.float32, device=dev)
+    full = [torch.empty_like(band) for _ in range(world)] if (world > 1 and rank == 0) else None
+    p_sum, p_sum2, p_cnt = band.data_ptr(), band.data_ptr() + 12 * npx, band.data_ptr() + 24 * npx
+    params = pt.RenderParams(W, H, r0, r1, 0, args.spp, MRR, 1e-4, -1.0, 42)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(timed):
+        band.zero_()
+        st = scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=True)
+        if world > 1:
+            dist.gather(band, full, dst=0)
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    stats = [step(True) for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        agg = torch.tensor([sum(s["kernel_ms"] for s in stats), float(sum(s["segments"] for s in stats)),
+                            float(sum(s["samples_traced"] for s in stats))], dtype=torch.float64, device=dev)
+        kmax = agg[:1].clone()
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        kernel_ms_rank0 = sum(s["kernel_ms"] for s in stats)
+    else:
+        kernel_ms_rank0 = sum(s["kernel_ms"] for s in stats)
+
+    if rank == 0:
+        k = max(args.steps, 1)
+        samples_per_step = W * H * args.spp
+        # dominant kernel on THIS rank: algorithmic flops per launch / HIP-event launch duration
+        seg = sum(s["segments"] for s in stats) / k
+        kms = kernel_ms_rank0 / k
+        achieved = seg * n_tri * FLOP_PER_TEST / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        algo_bytes = npx * 28 * 2 + n_tri * 112          # accumulators read + written once per launch, scene tables once
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+        if world == 1 and os.path.exists(pmc):
+            j = json.load(open(pmc))
+            if j.get("spp") == args.spp and j.get("width") == W and j.get("height") == H:
+                traffic = j.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Msamples/sec (WxHxspp/wall) on Tor.obj 1080p",
+            "value": samples_per_step * k / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / k * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (models/Tor.obj, 270 triangles, seed 42, counter RNG)",
+            "config": {"workload": f"Tor.obj {W}x{H} x {args.spp} spp, -MRR {MRR}, -ERR -1 (adaptive off), -EPS 1e-4; "
+                                   f"{world} row band(s) of {rows} rows" + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
+                       "width": W, "height": H, "spp": args.spp, "max_ray_reflections": MRR, "triangles": n_tri,
+                       "parallelism": f"rowband{world}"},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                         "kernel": "pt::integrate_kernel", "kernel_ms": kms, "segments_per_launch": seg,
+                         "flop_per_test": FLOP_PER_TEST,
+                         "hbm": {"algorithmic_bytes": algo_bytes, "achieved": algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": (algo_bytes / (kms * 1e-3) / 1e9) / PEAK_HBM_GBS if kms > 0 else 0.0}},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(models, args.cpu_seconds)
+        if args.write_bmp:
+            if world > 1:
+                parts = [t.cpu().numpy() for t in full]
+            else:
+                parts = [band.cpu().numpy()]
+            s = np.concatenate([p[:3 * npx] for p in parts]).reshape(-1, 3)
+            s2 = np.concatenate([p[3 * npx:6 * npx] for p in parts]).reshape(-1, 3)
+            c = np.concatenate([p[6 * npx:].view(np.int32) for p in parts])
+            bgr, disp = pt.resolve(W, H, s, s2, c)
+            pt.write_bmp(args.write_bmp, bgr)
+            out["config"]["dispersion_max_min_avg"] = [float(d) for d in disp]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
