@@ -79,7 +79,15 @@ struct Ray {
     float ox, oy, oz, dx, dy, dz;
 };
 
-__device__ __forceinline__ bool cull_reject(const CullRec &r, const Ray &q, float k1, float k2, float a_max, float m0,
+typedef const __attribute__((address_space(4))) float *ConstF;
+__device__ __forceinline__ CullRec load_cull(ConstF p) {
+    CullRec r;
+    r.n[0] = p[0]; r.n[1] = p[1]; r.n[2] = p[2]; r.w = p[3];
+    r.au[0] = p[4]; r.au[1] = p[5]; r.au[2] = p[6]; r.cu = p[7];
+    r.av[0] = p[8]; r.av[1] = p[9]; r.av[2] = p[10]; r.cv = p[11];
+    return r;
+}
+__device__ __forceinline__ bool cull_reject(const CullRec r, const Ray &q, float k1, float k2, float a_max, float m0,
                                             float t_guard) {
     const float num = __builtin_fmaf(q.ox, r.n[0], __builtin_fmaf(q.oy, r.n[1], __builtin_fmaf(q.oz, r.n[2], r.w)));
     const float den = __builtin_fmaf(q.dx, r.n[0], __builtin_fmaf(q.dy, r.n[1], q.dz * r.n[2]));
@@ -216,13 +224,14 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
                 const int nch = min(kTileChunks, a.n_chunks - tile0);
                 // ---- 1. cull
                 for (int c = 0; c < nch; ++c) {
-                    const CullRec *__restrict__ recs = a.cull + static_cast<size_t>(tile0 + c) * kChunk;
+                    // constant address space => scalar loads (the tables are never written while a kernel runs)
+                    ConstF recs = (ConstF)(reinterpret_cast<uintptr_t>(a.cull) + static_cast<size_t>(tile0 + c) * kChunk * sizeof(CullRec));
                     uint32_t m = 0;
                     // Four triangles per straight-line block: 48 SGPRs of records in flight; a full unroll makes the
                     // scheduler hoist all 32 scalar loads and spill hundreds of SGPRs.
 #pragma unroll 4
                     for (int j = 0; j < kChunk; ++j) {
-                        const bool rej = cull_reject(recs[j], q, k1, k2, a_max, m0, t_guard);
+                        const bool rej = cull_reject(load_cull(recs + 12 * j), q, k1, k2, a_max, m0, t_guard);
                         m |= rej ? 0u : (1u << j);
                     }
                     // the last word is padded with records that are never looked at
