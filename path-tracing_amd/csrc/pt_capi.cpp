@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -14,11 +15,23 @@
 #include "pt_kernels.hpp"
 #include "pt_scene.hpp"
 
+// Device copy of one CullTables (they depend on eps; a scene keeps the one of the last eps it rendered with).
+struct DeviceCull {
+    float eps = 0;
+    bool valid = false;
+    pt::CullTables host;
+    pt::ClusterDesc *clusters = nullptr;
+    pt::WordDesc *words = nullptr;
+    pt::SphereRec *spheres = nullptr;
+    pt::CullRec *bary = nullptr;
+};
+
 struct pt_scene {
     pt::HostScene host;
     pt::DeviceTables tables;
     int device = -1;
-    pt::CullRec *d_cull = nullptr;
+    DeviceCull cull;
+    std::mutex cull_mutex;
     pt::ExactRec *d_exact = nullptr;
     pt::MatRec *d_mats = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -54,15 +67,42 @@ int upload(pt_scene *s, int device) {
     s->device = device;
     PT_HIP_TRY(hipSetDevice(device));
     const auto &t = s->tables;
-    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_cull), t.cull.size() * sizeof(pt::CullRec) + 64));
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_exact), t.exact.size() * sizeof(pt::ExactRec) + 64));
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_mats), t.mats.size() * sizeof(pt::MatRec) + 64));
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 8 * sizeof(unsigned long long)));
-    if (!t.cull.empty()) PT_HIP_TRY(hipMemcpy(s->d_cull, t.cull.data(), t.cull.size() * sizeof(pt::CullRec), hipMemcpyHostToDevice));
     if (!t.exact.empty()) PT_HIP_TRY(hipMemcpy(s->d_exact, t.exact.data(), t.exact.size() * sizeof(pt::ExactRec), hipMemcpyHostToDevice));
     if (!t.mats.empty()) PT_HIP_TRY(hipMemcpy(s->d_mats, t.mats.data(), t.mats.size() * sizeof(pt::MatRec), hipMemcpyHostToDevice));
     PT_HIP_TRY(hipEventCreate(&s->ev0));
     PT_HIP_TRY(hipEventCreate(&s->ev1));
+    return PT_OK;
+}
+
+template <class T>
+int upload_vec(const std::vector<T> &v, T **dst) {
+    if (*dst) {
+        (void)hipFree(*dst);
+        *dst = nullptr;
+    }
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(T) + 256));
+    if (!v.empty()) PT_HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+// The cull hierarchy's radii and margins depend on eps (-EPS): build and upload on first use, rebuild if eps changes.
+int ensure_cull(pt_scene *s, float eps) {
+    std::lock_guard<std::mutex> lock(s->cull_mutex);
+    DeviceCull &c = s->cull;
+    if (c.valid && std::memcmp(&c.eps, &eps, sizeof eps) == 0) return PT_OK;
+    c.valid = false;
+    PT_HIP_TRY(hipDeviceSynchronize());   // a previous launch may still read the old tables
+    pt::build_cull_tables(s->host, eps, c.host);
+    int rc;
+    if ((rc = upload_vec(c.host.clusters, &c.clusters)) != PT_OK) return rc;
+    if ((rc = upload_vec(c.host.words, &c.words)) != PT_OK) return rc;
+    if ((rc = upload_vec(c.host.spheres, &c.spheres)) != PT_OK) return rc;
+    if ((rc = upload_vec(c.host.bary, &c.bary)) != PT_OK) return rc;
+    c.eps = eps;
+    c.valid = true;
     return PT_OK;
 }
 
@@ -162,7 +202,10 @@ void pt_scene_destroy(pt_scene *s) {
     if (!s) return;
     if (s->device >= 0) {
         (void)hipSetDevice(s->device);
-        if (s->d_cull) (void)hipFree(s->d_cull);
+        if (s->cull.clusters) (void)hipFree(s->cull.clusters);
+        if (s->cull.words) (void)hipFree(s->cull.words);
+        if (s->cull.spheres) (void)hipFree(s->cull.spheres);
+        if (s->cull.bary) (void)hipFree(s->cull.bary);
         if (s->d_exact) (void)hipFree(s->d_exact);
         if (s->d_mats) (void)hipFree(s->d_mats);
         if (s->d_stats) (void)hipFree(s->d_stats);
@@ -179,16 +222,21 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     if (!d_sum || !d_sum2 || !d_count) return fail(PT_ERR_INVALID_ARGUMENT, "null accumulator pointer");
     PT_HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const pt::CullConstants cc = pt::cull_constants(scene->tables.geo, p->eps);
+    const int crc = ensure_cull(scene, p->eps);
+    if (crc != PT_OK) return crc;
+    const pt::CullConstants cc = scene->cull.host.cc;
     pt::RenderArgs a;
-    a.cull = scene->d_cull;
+    a.clusters = scene->cull.clusters;
+    a.words = scene->cull.words;
+    a.spheres = scene->cull.spheres;
+    a.bary = scene->cull.bary;
     a.exact = scene->d_exact;
     a.mats = scene->d_mats;
     a.sum = d_sum;
     a.sum2 = d_sum2;
     a.count = d_count;
     a.stats = stats ? scene->d_stats : nullptr;
-    a.n_chunks = static_cast<int32_t>(scene->tables.cull.size() / pt::kChunk);
+    a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
     a.n_tri = scene->host.n_tri();
     a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
     a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;

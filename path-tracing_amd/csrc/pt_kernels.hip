@@ -2,10 +2,12 @@
 // all passes x segments x triangles of a row band in one launch.
 //
 // Per path segment a wave does three things:
-//   1. CULL   every triangle, wave-uniformly: the triangle's 12-float record comes in through scalar loads and is
-//             broadcast from SGPRs, the lanes' rays stay in VGPRs.  The test is a cheap CONSERVATIVE version of the
-//             reference's Triangle::Intersect (triangles.h:48-73): it may only say "cannot be a hit".  Survivors are
-//             recorded as one bit per triangle in per-lane mask words parked in LDS.
+//   1. CULL   wave-uniform walk over a three-level hierarchy of bounding spheres (cluster of 256 triangles -> octet of
+//             8 -> triangle); a node is skipped when no lane's ray comes near it.  Node records arrive through scalar
+//             loads and are used straight from SGPRs, the lanes' rays stay in VGPRs.  Large triangles (walls) get a
+//             barycentric test instead of a sphere.  Every test is CONSERVATIVE with respect to the reference's
+//             Triangle::Intersect (triangles.h:48-73): it may only say "cannot be a hit".  Survivors are recorded as
+//             one bit per triangle in per-lane mask words parked in LDS.
 //   2. EXACT  for the few survivors (about two per ray), each lane walks its own list in triangle order and runs the
 //             reference's arithmetic operation for operation (same association, no FMA contraction, IEEE divide and
 //             sqrt), so `t`, the hit decision and the closest-hit choice are bit-identical to the CPU path.
@@ -25,7 +27,7 @@ namespace pt {
 namespace {
 
 constexpr int kBlock = 256;               // 4 waves, each an independent 8x8 pixel tile
-constexpr int kTileChunks = 16;           // mask words kept in LDS per lane between cull and exact (512 triangles)
+constexpr int kSlots = 12;                // (mask word, first triangle) pairs kept in LDS per lane between cull and exact
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -87,6 +89,18 @@ __device__ __forceinline__ CullRec load_cull(ConstF p) {
     r.av[0] = p[8]; r.av[1] = p[9]; r.av[2] = p[10]; r.cv = p[11];
     return r;
 }
+typedef const __attribute__((address_space(4))) uint32_t *ConstU;
+
+// Keep the node iff the ray (not the whole line) comes within sqrt(r2) of the centre.  Written so that a NaN keeps.
+__device__ __forceinline__ bool sphere_keep(float cx, float cy, float cz, float r2, const Ray &q) {
+    const float mx = cx - q.ox, my = cy - q.oy, mz = cz - q.oz;
+    const float b = __builtin_fmaf(mx, q.dx, __builtin_fmaf(my, q.dy, mz * q.dz));
+    const float m2 = __builtin_fmaf(mx, mx, __builtin_fmaf(my, my, mz * mz));
+    const float bb = __builtin_fmaxf(b, 0.0f);
+    const float disc = __builtin_fmaf(-bb, bb, m2);
+    return !(disc > r2);
+}
+
 __device__ __forceinline__ bool cull_reject(const CullRec r, const Ray &q, float k1, float k2, float a_max, float m0,
                                             float t_guard) {
     const float num = __builtin_fmaf(q.ox, r.n[0], __builtin_fmaf(q.oy, r.n[1], __builtin_fmaf(q.oz, r.n[2], r.w)));
@@ -153,7 +167,7 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // The kernel
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
-    __shared__ uint32_t cand[kTileChunks][kBlock];
+    __shared__ uint2 cand[kSlots][kBlock];   // per lane: (candidate bits, index of the word's first triangle)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -220,43 +234,79 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
 
             float best = __builtin_inff();
             int hit = -1;
-            for (int tile0 = 0; tile0 < a.n_chunks; tile0 += kTileChunks) {
-                const int nch = min(kTileChunks, a.n_chunks - tile0);
-                // ---- 1. cull
-                for (int c = 0; c < nch; ++c) {
-                    // constant address space => scalar loads (the tables are never written while a kernel runs)
-                    ConstF recs = (ConstF)(reinterpret_cast<uintptr_t>(a.cull) + static_cast<size_t>(tile0 + c) * kChunk * sizeof(CullRec));
-                    uint32_t m = 0;
-                    // Four triangles per straight-line block: 48 SGPRs of records in flight; a full unroll makes the
-                    // scheduler hoist all 32 scalar loads and spill hundreds of SGPRs.
-#pragma unroll 4
-                    for (int j = 0; j < kChunk; ++j) {
-                        const bool rej = cull_reject(load_cull(recs + 12 * j), q, k1, k2, a_max, m0, t_guard);
-                        m |= rej ? 0u : (1u << j);
-                    }
-                    // the last word is padded with records that are never looked at
-                    const int left = a.n_tri - (tile0 + c) * kChunk;
-                    const uint32_t live = left >= kChunk ? 0xFFFFFFFFu : ((1u << left) - 1u);
-                    cand[c][tid] = valid ? (m & live) : 0u;
-                }
-                // ---- 2. exact, in triangle order (scene.cpp:116-120)
+            int n_slots = 0;   // wave-uniform
+
+            // ---- 2. exact, in triangle order (scene.cpp:116-120), over the words parked so far
+            auto run_exact = [&]() {
                 int c = -1;
-                uint32_t m = 0;
+                uint32_t m = 0, first = 0;
                 for (;;) {
-                    while (m == 0 && c + 1 < nch) {
+                    while (m == 0 && c + 1 < n_slots) {
                         ++c;
-                        m = cand[c][tid];
+                        const uint2 e = cand[c][tid];
+                        m = e.x;
+                        first = e.y;
                     }
                     if (!__any(m != 0)) break;
                     if (m != 0) {
                         const int j = __builtin_ctz(m);
                         m &= m - 1;
-                        const int i = (tile0 + c) * kChunk + j;
+                        const int i = static_cast<int>(first) + j;
                         if (exact_intersect(a.exact + i, q, eps, best)) hit = i;
                         ++n_exact;
                     }
                 }
+                n_slots = 0;
+            };
+
+            // ---- 1. cull
+            const ConstF clusters = (ConstF)reinterpret_cast<uintptr_t>(a.clusters);
+            const ConstU words = (ConstU)reinterpret_cast<uintptr_t>(a.words);
+            const ConstF spheres = (ConstF)reinterpret_cast<uintptr_t>(a.spheres);
+            const ConstF bary = (ConstF)reinterpret_cast<uintptr_t>(a.bary);
+            for (int cl = 0; cl < a.n_clusters; ++cl) {
+                const ConstF cp = clusters + 8 * cl;
+                const bool pc = valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q);
+                if (!__any(pc)) continue;
+                const uint32_t w0 = ((ConstU)cp)[4], w1 = w0 + ((ConstU)cp)[5];
+                for (uint32_t w = w0; w < w1; ++w) {
+                    const ConstU wd = words + 4 * w;
+                    const uint32_t first = wd[0], count = wd[1], kind = wd[2], off = wd[3];
+                    uint32_t m = 0;
+                    if (kind == 0) {
+                        const ConstF sp = spheres + 4 * static_cast<size_t>(off);
+                        for (int o = 0; o < kChunk / kOctet; ++o) {
+                            const bool po = pc & sphere_keep(sp[4 * o], sp[4 * o + 1], sp[4 * o + 2], sp[4 * o + 3], q);
+                            if (!__any(po)) continue;
+                            const ConstF tp = sp + 4 * (kChunk / kOctet) + 4 * kOctet * o;
+                            uint32_t mo = 0;
+#pragma unroll
+                            for (int k = 0; k < kOctet; ++k) {
+                                const bool pt = sphere_keep(tp[4 * k], tp[4 * k + 1], tp[4 * k + 2], tp[4 * k + 3], q);
+                                mo |= pt ? (1u << k) : 0u;
+                            }
+                            m |= (po ? mo : 0u) << (kOctet * o);
+                        }
+                    } else {
+                        const ConstF bp = bary + 12 * static_cast<size_t>(off);
+                        for (uint32_t k0 = 0; k0 < count; k0 += 4) {   // records are padded to whole words
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
+                                m |= rej ? 0u : (1u << (k0 + j));
+                            }
+                        }
+                        m = pc ? m : 0u;
+                    }
+                    m &= count >= 32u ? 0xFFFFFFFFu : ((1u << count) - 1u);   // padding records are never candidates
+                    if (__any(m != 0)) {
+                        cand[n_slots][tid] = make_uint2(m, first);
+                        ++n_slots;
+                        if (n_slots == kSlots) run_exact();
+                    }
+                }
             }
+            run_exact();
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
             if (valid) {

@@ -11,13 +11,16 @@ namespace pt {
 constexpr uint32_t kPhiloxKey1 = 0x50544831u;   // "PTH1": second Philox key word (the first is the seed)
 
 struct RenderArgs {
-    const CullRec *cull;      // n_chunks * kChunk records
+    const ClusterDesc *clusters;   // cull hierarchy (pt_scene.hpp: CullTables), read through the scalar cache
+    const WordDesc *words;
+    const SphereRec *spheres;
+    const CullRec *bary;
     const ExactRec *exact;    // n_tri
     const MatRec *mats;
     float *sum, *sum2;        // row band, 3 floats per pixel
     int32_t *count;
     unsigned long long *stats;   // 5 counters or nullptr
-    int32_t n_chunks, n_tri;
+    int32_t n_clusters, n_tri;
     int32_t width, height, row_begin, row_end;
     int32_t pass_begin, pass_count, mrr;
     float eps, error;

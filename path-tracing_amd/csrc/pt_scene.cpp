@@ -163,9 +163,6 @@ bool load_obj(const std::string &dir, const std::string &name, HostScene &out, s
 void build_device_tables(const HostScene &s, DeviceTables &out) {
     const int T = s.n_tri();
     out.exact.resize(T);
-    out.cull.clear();
-    out.geo = CullGeometry();
-    out.geo.r_max = 20.0;   // the camera origin (0,0,-20), main.cpp:129
     for (int i = 0; i < T; ++i) {
         const float *r = &s.tri[14 * static_cast<size_t>(i)];
         ExactRec &e = out.exact[i];
@@ -176,45 +173,6 @@ void build_device_tables(const HostScene &s, DeviceTables &out) {
         e.material = s.tri_mat[i];
         std::memcpy(e.v2, r + 10, 12);
         e.pad = 0.0f;
-
-        // Barycentric functions of the orthogonal projection onto the triangle's own plane, in double.
-        const double v0[3] = {r[4], r[5], r[6]}, v1[3] = {r[7], r[8], r[9]}, v2[3] = {r[10], r[11], r[12]};
-        const double e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
-        const double e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
-        const double e3[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        const double nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        const double s2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
-        const double area2 = std::sqrt(s2);   // parallelogram area S
-        double au[3], av[3];
-        au[0] = (e2[1] * nn[2] - e2[2] * nn[1]) / s2;
-        au[1] = (e2[2] * nn[0] - e2[0] * nn[2]) / s2;
-        au[2] = (e2[0] * nn[1] - e2[1] * nn[0]) / s2;
-        av[0] = (nn[1] * e1[2] - nn[2] * e1[1]) / s2;
-        av[1] = (nn[2] * e1[0] - nn[0] * e1[2]) / s2;
-        av[2] = (nn[0] * e1[1] - nn[1] * e1[0]) / s2;
-        CullRec c;
-        c.n[0] = r[0]; c.n[1] = r[1]; c.n[2] = r[2]; c.w = r[3];
-        for (int k = 0; k < 3; ++k) { c.au[k] = static_cast<float>(au[k]); c.av[k] = static_cast<float>(av[k]); }
-        c.cu = static_cast<float>(-(au[0] * v0[0] + au[1] * v0[1] + au[2] * v0[2]));
-        c.cv = static_cast<float>(-(av[0] * v0[0] + av[1] * v0[1] + av[2] * v0[2]));
-        out.cull.push_back(c);
-
-        auto len = [](const double *a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
-        const double aw[3] = {au[0] + av[0], au[1] + av[1], au[2] + av[2]};
-        const double amax = std::max(len(au), std::max(len(av), len(aw)));
-        const double diam = std::max(len(e1), std::max(len(e2), len(e3)));
-        if (std::isfinite(amax)) out.geo.a_max = std::max(out.geo.a_max, amax);
-        if (area2 > 0) {
-            out.geo.inv_2s_max = std::max(out.geo.inv_2s_max, 1.0 / (2.0 * area2));
-            out.geo.diam2_2s_max = std::max(out.geo.diam2_2s_max, diam * diam / (2.0 * area2));
-        }
-        for (int k = 4; k < 13; ++k) out.geo.r_max = std::max(out.geo.r_max, static_cast<double>(std::fabs(r[k])));
-    }
-    // Pad to whole mask words; the kernel masks the padding bits off, the records only have to be readable.
-    while (out.cull.size() % kChunk) {
-        CullRec c;
-        std::memset(&c, 0, sizeof c);
-        out.cull.push_back(c);
     }
     out.mats.resize(s.n_mat());
     for (int m = 0; m < s.n_mat(); ++m) {   // Factory, material.h:58-106
@@ -240,20 +198,224 @@ void build_device_tables(const HostScene &s, DeviceTables &out) {
     }
 }
 
-CullConstants cull_constants(const CullGeometry &g, float eps) {
-    // u = unit roundoff of binary32.  Derivation in DESIGN.md ("Culling: why it cannot reject a hit").
-    const double u = 5.9604644775390625e-08;
-    const double r = g.r_max + 1.0;                 // ray origins sit on surfaces, offset by eps*N
-    const double m_abs = 2.0 * std::sqrt(3.0) * r;  // bound on |o.n| + |w|
-    CullConstants c;
-    c.k2 = static_cast<float>(12.0 * u * m_abs + 8.0 * u * r);
-    c.k1 = static_cast<float>(40.0 * u);
-    c.a_max = static_cast<float>(g.a_max * (1.0 + 1e-6));
-    const double e_fp = 40.0 * u * g.diam2_2s_max;   // float error of the reference's area sum, already /(2S)
-    c.m0 = static_cast<float>(std::fabs(static_cast<double>(eps)) * g.inv_2s_max * 1.01 + e_fp
-                              + 16.0 * u * g.a_max * r * std::sqrt(3.0) + 1e-6);
-    c.t_guard = static_cast<float>(4096.0 * r);
-    return c;
+namespace {
+
+struct V3 {
+    double x, y, z;
+};
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 crs(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double dt(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline double nrm(V3 a) { return std::sqrt(dt(a, a)); }
+
+// What an accepted hit point of one triangle can be, in exact arithmetic (DESIGN.md "Culling"):
+// barycentric coordinates >= -m_geo, distance from the triangle's own plane <= h_max.
+struct TriGeo {
+    V3 v[3];
+    double area2;    // parallelogram area S
+    double diam;     // longest edge
+    double m_geo;    // (eps + E_fp) / (2 S)
+    double h_max;    // sqrt(2 S E + E^2) / perimeter
+    double a_max;    // largest barycentric gradient
+    bool degenerate;
+};
+
+const double kU = 5.9604644775390625e-08;   // unit roundoff of binary32
+
+TriGeo tri_geometry(const float *r, double eps) {
+    TriGeo g;
+    g.v[0] = {r[4], r[5], r[6]};
+    g.v[1] = {r[7], r[8], r[9]};
+    g.v[2] = {r[10], r[11], r[12]};
+    const V3 e1 = sub(g.v[1], g.v[0]), e2 = sub(g.v[2], g.v[0]), e3 = sub(g.v[2], g.v[1]);
+    g.area2 = nrm(crs(e1, e2));
+    g.diam = std::max(nrm(e1), std::max(nrm(e2), nrm(e3)));
+    const double perim = nrm(e1) + nrm(e2) + nrm(e3);
+    // float error of the reference's |S - s1 - s2 - s3| for a point near the triangle: three cross products of
+    // vectors no longer than ~diam, three lengths, three subtractions
+    const double e_fp = 40.0 * kU * (g.diam + 1e-3) * (g.diam + 1e-3);
+    const double big_e = std::fabs(eps) + e_fp;
+    // A triangle whose area is within a few eps of zero is accepted by the reference for points that have nothing to
+    // do with it (all three computed sub-areas can vanish far away): never cull it.
+    g.degenerate = !(g.area2 > 4.0 * big_e) || !std::isfinite(g.area2) || !std::isfinite(g.diam);
+    if (g.degenerate) {
+        g.m_geo = g.h_max = g.a_max = INFINITY;
+    } else {
+        g.m_geo = big_e / (2.0 * g.area2);
+        g.h_max = std::sqrt(2.0 * g.area2 * big_e + big_e * big_e) / perim;
+        g.a_max = g.diam / g.area2;   // gradients of the barycentric functions are 1/height; smallest height = S/diam
+    }
+    return g;
+}
+
+// Ritter's bounding sphere of a point set, then grown to cover every point exactly.
+void bounding_sphere(const std::vector<V3> &pts, V3 &c, double &rad) {
+    if (pts.empty()) { c = {0, 0, 0}; rad = 0; return; }
+    auto far_from = [&](V3 p) {
+        size_t best = 0; double bd = -1;
+        for (size_t i = 0; i < pts.size(); ++i) { const double d = nrm(sub(pts[i], p)); if (d > bd) { bd = d; best = i; } }
+        return best;
+    };
+    const V3 a = pts[far_from(pts[0])];
+    const V3 b = pts[far_from(a)];
+    c = {(a.x + b.x) / 2, (a.y + b.y) / 2, (a.z + b.z) / 2};
+    rad = nrm(sub(a, b)) / 2;
+    for (int it = 0; it < 2; ++it)
+        for (const V3 &p : pts) {
+            const V3 d = sub(p, c);
+            const double dist = nrm(d);
+            if (dist > rad) {
+                const double nr = (rad + dist) / 2, k = (nr - rad) / dist;
+                c = {c.x + d.x * k, c.y + d.y * k, c.z + d.z * k};
+                rad = nr;
+            }
+        }
+    for (const V3 &p : pts) rad = std::max(rad, nrm(sub(p, c)));
+}
+
+}  // namespace
+
+void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
+    const int T = s.n_tri();
+    const double eps = eps_f;
+    out = CullTables();
+    out.eps = eps_f;
+
+    // ---- scene-wide bounds
+    double r_max = 20.0;   // the camera origin (0,0,-20), main.cpp:129
+    for (int i = 0; i < T; ++i)
+        for (int k = 4; k < 13; ++k) r_max = std::max(r_max, static_cast<double>(std::fabs(s.tri[14 * static_cast<size_t>(i) + k])));
+    const double r_org = r_max + 1.0;                       // ray origins sit on surfaces, offset by eps*N
+    const double d_max = 2.0 * std::sqrt(3.0) * r_org;      // bound on |c - o| for c, o inside the scene box
+    // rounding of P* = o + d*t* (per component <= u(2|t| + |o|)) and of the centre-to-origin vector
+    const double eps_line = 8.0 * kU * (d_max + r_org);
+    // float error of disc = |m|^2 - (m.d)^2 in the kernel, plus |d| != 1 by a few ulp
+    const double disc_err = 24.0 * kU * d_max * d_max;
+
+    std::vector<TriGeo> geo(T);
+    for (int i = 0; i < T; ++i) geo[i] = tri_geometry(&s.tri[14 * static_cast<size_t>(i)], eps);
+
+    auto sphere_of = [&](int first, int count, SphereRec &rec) {
+        std::vector<V3> pts;
+        bool inf = false;
+        for (int i = first; i < first + count; ++i) {
+            if (geo[i].degenerate) inf = true;
+            for (const V3 &v : geo[i].v) pts.push_back(v);
+        }
+        V3 c; double rad;
+        bounding_sphere(pts, c, rad);
+        double reff = 0;
+        for (int i = first; i < first + count && !inf; ++i) {
+            double dmax = 0;
+            for (const V3 &v : geo[i].v) dmax = std::max(dmax, nrm(sub(v, c)));
+            // accepted point = sum(lambda_k v_k) + h n, lambda_k >= -m_geo  =>  |P - c| <= (1 + 4 m_geo) dmax + h_max
+            reff = std::max(reff, (1.0 + 4.0 * geo[i].m_geo) * dmax + geo[i].h_max + eps_line);
+        }
+        rec.c[0] = static_cast<float>(c.x); rec.c[1] = static_cast<float>(c.y); rec.c[2] = static_cast<float>(c.z);
+        // the centre is rounded to float: grow by that displacement
+        const double c_round = nrm(sub(c, V3{rec.c[0], rec.c[1], rec.c[2]}));
+        const double r2 = (reff + c_round) * (reff + c_round) * (1.0 + 1e-6) + disc_err;
+        rec.r2 = (inf || !std::isfinite(r2)) ? INFINITY : static_cast<float>(r2 * (1.0 + 2e-7));
+        return inf ? INFINITY : reff;
+    };
+
+    // ---- classes: a triangle whose own sphere is a sizeable part of the scene is culled by the barycentric test
+    std::vector<uint8_t> large(T);
+    double a_max = 0, inv_2s_max = 0, diam2_2s_max = 0;
+    for (int i = 0; i < T; ++i) {
+        SphereRec tmp;
+        const double reff = sphere_of(i, 1, tmp);
+        large[i] = !(reff < 0.12 * r_max);
+    }
+    // ---- words (<= 32 consecutive triangles of one class), clusters (<= 8 consecutive words of one class)
+    const SphereRec never = {{0, 0, 0}, -1.0e30f};
+    int i = 0;
+    while (i < T) {
+        const bool lg = large[i];
+        int n = 1;
+        while (i + n < T && n < kChunk && large[i + n] == lg) ++n;
+        WordDesc w;
+        w.first_tri = static_cast<uint32_t>(i);
+        w.count = static_cast<uint32_t>(n);
+        w.kind = lg ? 1u : 0u;
+        if (!lg) {
+            w.data_off = static_cast<uint32_t>(out.spheres.size());
+            for (int o = 0; o < kChunk / kOctet; ++o) {
+                SphereRec sr = never;
+                const int f = i + o * kOctet, c = std::min(kOctet, i + n - f);
+                if (c > 0) sphere_of(f, c, sr);
+                out.spheres.push_back(sr);
+            }
+            for (int k = 0; k < kChunk; ++k) {
+                SphereRec sr = never;
+                if (k < n) sphere_of(i + k, 1, sr);
+                out.spheres.push_back(sr);
+            }
+        } else {
+            w.data_off = static_cast<uint32_t>(out.bary.size());
+            for (int k = 0; k < kChunk; ++k) {
+                CullRec c;
+                std::memset(&c, 0, sizeof c);
+                if (k < n) {
+                    const float *r = &s.tri[14 * static_cast<size_t>(i + k)];
+                    const TriGeo &g = geo[i + k];
+                    const V3 e1 = sub(g.v[1], g.v[0]), e2 = sub(g.v[2], g.v[0]);
+                    const V3 nn = crs(e1, e2);
+                    const double s2 = dt(nn, nn);
+                    const V3 au = {crs(e2, nn).x / s2, crs(e2, nn).y / s2, crs(e2, nn).z / s2};
+                    const V3 av = {crs(nn, e1).x / s2, crs(nn, e1).y / s2, crs(nn, e1).z / s2};
+                    c.n[0] = r[0]; c.n[1] = r[1]; c.n[2] = r[2]; c.w = r[3];
+                    c.au[0] = static_cast<float>(au.x); c.au[1] = static_cast<float>(au.y); c.au[2] = static_cast<float>(au.z);
+                    c.av[0] = static_cast<float>(av.x); c.av[1] = static_cast<float>(av.y); c.av[2] = static_cast<float>(av.z);
+                    c.cu = static_cast<float>(-dt(au, g.v[0]));
+                    c.cv = static_cast<float>(-dt(av, g.v[0]));
+                    if (g.degenerate) {
+                        // NaN coefficients make every comparison of the cull test false: the triangle is always kept
+                        c.au[0] = c.au[1] = c.au[2] = c.av[0] = c.av[1] = c.av[2] = c.cu = c.cv = NAN;
+                    } else {
+                        a_max = std::max(a_max, g.a_max);
+                        inv_2s_max = std::max(inv_2s_max, 1.0 / (2.0 * g.area2));
+                        diam2_2s_max = std::max(diam2_2s_max, g.diam * g.diam / (2.0 * g.area2));
+                    }
+                }
+                out.bary.push_back(c);
+            }
+        }
+        out.words.push_back(w);
+        i += n;
+    }
+    size_t wi = 0;
+    while (wi < out.words.size()) {
+        const uint32_t kind = out.words[wi].kind;
+        size_t n = 1;
+        while (wi + n < out.words.size() && n < static_cast<size_t>(kClusterWords) && out.words[wi + n].kind == kind) ++n;
+        ClusterDesc c;
+        std::memset(&c, 0, sizeof c);
+        c.first_word = static_cast<uint32_t>(wi);
+        c.n_words = static_cast<uint32_t>(n);
+        const int first = static_cast<int>(out.words[wi].first_tri);
+        const int last = static_cast<int>(out.words[wi + n - 1].first_tri + out.words[wi + n - 1].count);
+        SphereRec sr;
+        sphere_of(first, last - first, sr);
+        c.c[0] = sr.c[0]; c.c[1] = sr.c[1]; c.c[2] = sr.c[2]; c.r2 = sr.r2;
+        out.clusters.push_back(c);
+        wi += n;
+    }
+    // keep the tables non-empty and padded so that speculative wide scalar loads stay inside the allocation
+    for (int k = 0; k < 16; ++k) out.spheres.push_back(never);
+    for (int k = 0; k < 4; ++k) { CullRec c; std::memset(&c, 0, sizeof c); out.bary.push_back(c); }
+
+    // ---- margins of the barycentric test (large triangles)
+    const double m_abs = 2.0 * std::sqrt(3.0) * r_org;   // bound on |o.n| + |w|
+    CullConstants &cc = out.cc;
+    cc.k2 = static_cast<float>(12.0 * kU * m_abs + 8.0 * kU * r_org);
+    cc.k1 = static_cast<float>(40.0 * kU);
+    cc.a_max = static_cast<float>(a_max * (1.0 + 1e-6));
+    cc.m0 = static_cast<float>(std::fabs(eps) * inv_2s_max * 1.01 + 40.0 * kU * diam2_2s_max
+                               + 16.0 * kU * a_max * r_org * std::sqrt(3.0) + 1e-6);
+    double tg = 4096.0 * r_org;
+    if (a_max > 0) tg = std::min(tg, 1.0e6 / a_max);   // keep the reference's own area arithmetic meaningful
+    cc.t_guard = static_cast<float>(tg);
 }
 
 }  // namespace pt

@@ -50,31 +50,49 @@ struct MatRec {
 };
 
 static const int kChunk = 32;   // triangles per candidate-mask word
+static const int kOctet = 8;    // triangles per sub-group of a word (its own bounding sphere)
+static const int kClusterWords = 8;   // words per cluster (256 triangles)
 
-// Geometry statistics from which the culling margins are derived for a given eps (see DESIGN.md "Culling").
-struct CullGeometry {
-    double r_max = 0;          // largest |coordinate| of any vertex or of the camera origin
-    double a_max = 0;          // largest gradient of any barycentric function (1 / smallest triangle height)
-    double inv_2s_max = 0;     // max over triangles of 1/(2*S)
-    double diam2_2s_max = 0;   // max over triangles of diam^2/(2*S)
+// Bounding sphere used by the hierarchical cull: a ray is kept for the node iff its distance to `c` is <= sqrt(r2).
+// r2 already contains every slack that makes the test conservative (see DESIGN.md "Culling").
+struct SphereRec {
+    float c[3], r2;
+};
+// One candidate-mask word = up to 32 consecutive triangles of one class.
+//   kind 0 (small triangles): data_off indexes SphereRec: 4 octet spheres, then 32 triangle spheres
+//   kind 1 (large triangles): data_off indexes CullRec (one barycentric cull record per triangle, padded to 32)
+struct WordDesc {
+    uint32_t first_tri, count, kind, data_off;
+};
+struct ClusterDesc {
+    float c[3], r2;
+    uint32_t first_word, n_words, pad0, pad1;
 };
 
-struct DeviceTables {
-    std::vector<CullRec> cull;     // padded with zero records to a multiple of kChunk
-    std::vector<ExactRec> exact;   // n_tri
-    std::vector<MatRec> mats;      // n_mat
-    CullGeometry geo;
-};
-
-void build_device_tables(const HostScene &s, DeviceTables &out);
-
-// Margins of the conservative cull test for one render call (depend on eps).
+// Margins of the barycentric cull test for one render call (depend on eps).
 struct CullConstants {
     float k1, k2;     // |t_cull - t_reference| <= (k2 + k1*|t|) / |n.d|
     float a_max;      // scales a distance error into barycentric units
     float m0;         // barycentric slack an accepted point can have (eps / area, float error of the area sum)
     float t_guard;    // beyond this |t| the cull test abstains
 };
-CullConstants cull_constants(const CullGeometry &g, float eps);
+
+// Everything the cull stage reads; depends on eps, so a scene caches one set per eps value.
+struct CullTables {
+    std::vector<SphereRec> spheres;
+    std::vector<CullRec> bary;
+    std::vector<WordDesc> words;
+    std::vector<ClusterDesc> clusters;
+    CullConstants cc;
+    float eps = 0;
+};
+
+struct DeviceTables {
+    std::vector<ExactRec> exact;   // n_tri
+    std::vector<MatRec> mats;      // n_mat
+};
+
+void build_device_tables(const HostScene &s, DeviceTables &out);
+void build_cull_tables(const HostScene &s, float eps, CullTables &out);
 
 }  // namespace pt
