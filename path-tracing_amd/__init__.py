@@ -40,7 +40,8 @@ class RenderParams(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("samples_traced", C.c_uint64), ("segments", C.c_uint64), ("contributing", C.c_uint64),
-                ("exact_tests", C.c_uint64), ("misses", C.c_uint64), ("kernel_ms", C.c_float),
+                ("exact_tests", C.c_uint64), ("misses", C.c_uint64), ("wave_segments", C.c_uint64),
+                ("wave_octets", C.c_uint64), ("wave_exact_iterations", C.c_uint64), ("kernel_ms", C.c_float),
                 ("n_triangles", C.c_int32)]
 
     def as_dict(self):

@@ -21,7 +21,6 @@ struct DeviceCull {
     bool valid = false;
     pt::CullTables host;
     pt::ClusterDesc *clusters = nullptr;
-    pt::WordDesc *words = nullptr;
     pt::SphereRec *spheres = nullptr;
     pt::CullRec *bary = nullptr;
 };
@@ -98,7 +97,6 @@ int ensure_cull(pt_scene *s, float eps) {
     pt::build_cull_tables(s->host, eps, c.host);
     int rc;
     if ((rc = upload_vec(c.host.clusters, &c.clusters)) != PT_OK) return rc;
-    if ((rc = upload_vec(c.host.words, &c.words)) != PT_OK) return rc;
     if ((rc = upload_vec(c.host.spheres, &c.spheres)) != PT_OK) return rc;
     if ((rc = upload_vec(c.host.bary, &c.bary)) != PT_OK) return rc;
     c.eps = eps;
@@ -203,7 +201,6 @@ void pt_scene_destroy(pt_scene *s) {
     if (s->device >= 0) {
         (void)hipSetDevice(s->device);
         if (s->cull.clusters) (void)hipFree(s->cull.clusters);
-        if (s->cull.words) (void)hipFree(s->cull.words);
         if (s->cull.spheres) (void)hipFree(s->cull.spheres);
         if (s->cull.bary) (void)hipFree(s->cull.bary);
         if (s->d_exact) (void)hipFree(s->d_exact);
@@ -227,7 +224,6 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     const pt::CullConstants cc = scene->cull.host.cc;
     pt::RenderArgs a;
     a.clusters = scene->cull.clusters;
-    a.words = scene->cull.words;
     a.spheres = scene->cull.spheres;
     a.bary = scene->cull.bary;
     a.exact = scene->d_exact;
@@ -242,7 +238,7 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
     a.eps = p->eps; a.error = p->error; a.seed = p->seed;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
-    a.blocks_x = (p->width + 15) / 16;
+    a.blocks_x = (p->width + 7) / 8;
     if (stats) {
         PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 8 * sizeof(unsigned long long), stream));
         PT_HIP_TRY(hipEventRecord(scene->ev0, stream));
@@ -260,6 +256,9 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
         stats->contributing = h[2];
         stats->exact_tests = h[3];
         stats->misses = h[4];
+        stats->wave_segments = h[5];
+        stats->wave_octets = h[6];
+        stats->wave_exact_iterations = h[7];
         stats->kernel_ms = ms;
         stats->n_triangles = scene->host.n_tri();
     }

@@ -26,8 +26,9 @@ namespace pt {
 
 namespace {
 
-constexpr int kBlock = 256;               // 4 waves, each an independent 8x8 pixel tile
-constexpr int kSlots = 12;                // (mask word, first triangle) pairs kept in LDS per lane between cull and exact
+constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per workgroup (all LDS below is wave-private)
+constexpr int kSlots = 16;                // candidate-mask words (32 triangles each) parked per lane between cull and exact
+constexpr int kQueue = 256;               // work items per batch of the two lane-balanced queues
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -156,6 +157,44 @@ __device__ __forceinline__ bool exact_intersect(const ExactRec *__restrict__ rec
     return hit;
 }
 
+// Stages B-D of Triangle::Intersect for one (ray, triangle) pair, without the running `distance`:
+// returns new_distance if the point passes the area tests, -inf otherwise (then stage A rejects it: -inf < eps).
+__device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, const Ray &q, float eps) {
+    const float4 r0 = reinterpret_cast<const float4 *>(rec)[0];   // plane
+    const float4 r1 = reinterpret_cast<const float4 *>(rec)[1];   // v0, square
+    const float4 r2 = reinterpret_cast<const float4 *>(rec)[2];   // v1, material
+    const float4 r3 = reinterpret_cast<const float4 *>(rec)[3];   // v2
+    const float signed_dist = q.dx * r0.x + q.dy * r0.y + q.dz * r0.z;
+    const float nd = -(q.ox * r0.x + q.oy * r0.y + q.oz * r0.z + r0.w) / signed_dist;
+    const float px = q.ox + q.dx * nd, py = q.oy + q.dy * nd, pz = q.oz + q.dz * nd;
+    const float f0x = px - r1.x, f0y = py - r1.y, f0z = pz - r1.z;
+    const float f1x = px - r2.x, f1y = py - r2.y, f1z = pz - r2.z;
+    const float f2x = px - r3.x, f2y = py - r3.y, f2z = pz - r3.z;
+    const float sq = r1.w;
+    const float s1 = area_of(f0x, f0y, f0z, f1x, f1y, f1z);
+    const bool stage_b = !(s1 > sq + eps);
+    const float s2 = area_of(f0x, f0y, f0z, f2x, f2y, f2z);
+    const bool stage_c = !(s1 + s2 > sq + eps);
+    const float s3 = area_of(f2x, f2y, f2z, f1x, f1y, f1z);
+    const bool stage_d = !(__builtin_fabsf(sq - s1 - s2 - s3) > eps);
+    return (stage_b && stage_c && stage_d) ? nd : -__builtin_inff();
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// LDS traffic between lanes of ONE wave: the hardware executes a wave's LDS instructions in order, so only the
+// compiler has to be stopped from moving them across the hand-off.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // glm::normalize(vec4(x,y,z,0))
     const float inv = 1.0f / __builtin_sqrtf((x * x + y * y) + z * z);
     x = x * inv; y = y * inv; z = z * inv;
@@ -167,14 +206,16 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // The kernel
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
-    __shared__ uint2 cand[kSlots][kBlock];   // per lane: (candidate bits, index of the word's first triangle)
+    __shared__ uint32_t s_cand[kSlots][64];   // per lane: candidate bits of one 32-triangle word
+    __shared__ uint32_t s_first[kSlots];      // index of the word's first triangle
+    __shared__ uint32_t s_live[kSlots];       // bits of the word that are real triangles
+    __shared__ float s_ray[6][64];            // this segment's rays, readable by every lane
+    __shared__ uint32_t s_queue[kQueue];      // work items: (octet | lane << 8) or (triangle | lane << 24)
+    __shared__ float s_res[kQueue];           // per (ray, triangle) item: t if inside, -inf otherwise
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    // block = 16x16 pixels, wave = 8x8
-    const int bx = blockIdx.x % a.blocks_x, by = blockIdx.x / a.blocks_x;
-    const int x = bx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = a.row_begin + by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int lane = threadIdx.x;
+    const int x = (blockIdx.x % a.blocks_x) * 8 + (lane & 7);
+    const int y = a.row_begin + (blockIdx.x / a.blocks_x) * 8 + (lane >> 3);
     const bool in_image = x < a.width && y < a.row_end;
     const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
     const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
@@ -187,6 +228,7 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
         cnt = a.count[p];
     }
     uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_exact = 0, n_miss = 0;
+    uint32_t w_segments = 0, w_octets = 0, w_exact_iters = 0;   // wave-level (uniform) diagnostics
 
     const int mrr = a.mrr;
     const float eps = a.eps;
@@ -232,64 +274,147 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
             const bool valid = depth < mrr && (tr != 0.0f || tg != 0.0f || tb != 0.0f);   // Ray::IsValid, ray.h:52-54
             if (!__any(valid)) break;
 
+            ++w_segments;
             float best = __builtin_inff();
             int hit = -1;
             int n_slots = 0;   // wave-uniform
 
-            // ---- 2. exact, in triangle order (scene.cpp:116-120), over the words parked so far
-            auto run_exact = [&]() {
-                int c = -1;
-                uint32_t m = 0, first = 0;
-                for (;;) {
-                    while (m == 0 && c + 1 < n_slots) {
-                        ++c;
-                        const uint2 e = cand[c][tid];
-                        m = e.x;
-                        first = e.y;
-                    }
-                    if (!__any(m != 0)) break;
-                    if (m != 0) {
-                        const int j = __builtin_ctz(m);
+            // every lane's ray, for the lane-balanced phases
+            s_ray[0][lane] = q.ox; s_ray[1][lane] = q.oy; s_ray[2][lane] = q.oz;
+            s_ray[3][lane] = q.dx; s_ray[4][lane] = q.dy; s_ray[5][lane] = q.dz;
+
+            // ---- 2. exact.  The candidates parked in s_cand are spread evenly over the lanes (a lane works on other
+            // lanes' rays), each (ray, triangle) pair yields t and the outcome of stages B-D of Triangle::Intersect,
+            // and every lane then replays its own pairs in triangle order with the reference's running `distance`
+            // (stage A, triangles.h:51), so the closest-hit choice is the reference's, ties and NaNs included.
+            auto flush = [&]() {
+                uint32_t mine = 0;
+                for (int sl = 0; sl < n_slots; ++sl) {
+                    const uint32_t m = s_cand[sl][lane] & s_live[sl];
+                    s_cand[sl][lane] = m;
+                    mine += __builtin_popcount(m);
+                }
+                const uint32_t incl = wave_inclusive_scan(mine, lane);
+                const uint32_t start = incl - mine;
+                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                int c = -1;            // cursor over this lane's candidates
+                uint32_t m = 0, k = 0;
+                for (uint32_t base = 0; base < total; base += kQueue) {
+                    const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
+                    // (a) publish this lane's pairs that fall into the batch, in triangle order
+                    const uint32_t k_first = k;
+                    while (k < mine && start + k < base + kQueue) {
+                        while (m == 0) { ++c; m = s_cand[c][lane]; }
+                        const uint32_t j = __builtin_ctz(m);
                         m &= m - 1;
-                        const int i = static_cast<int>(first) + j;
-                        if (exact_intersect(a.exact + i, q, eps, best)) hit = i;
-                        ++n_exact;
+                        s_queue[start + k - base] = (s_first[c] + j) | (static_cast<uint32_t>(lane) << 24);
+                        ++k;
                     }
+                    wave_sync();
+                    // (b) balanced: lane l takes pairs l, l+64, ...
+                    for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
+                        ++w_exact_iters;
+                        const uint32_t i = i0 + lane;
+                        if (i < n_in) {
+                            const uint32_t e = s_queue[i];
+                            const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
+                            Ray r;
+                            r.ox = s_ray[0][src]; r.oy = s_ray[1][src]; r.oz = s_ray[2][src];
+                            r.dx = s_ray[3][src]; r.dy = s_ray[4][src]; r.dz = s_ray[5][src];
+                            s_res[i] = exact_inside(a.exact + tri, r, eps);
+                            ++n_exact;
+                        }
+                    }
+                    wave_sync();
+                    // (c) replay in triangle order (scene.cpp:116-120 with the stage-A test of triangles.h:51)
+                    for (uint32_t kk = k_first; kk < k; ++kk) {
+                        const float nd = s_res[start + kk - base];
+                        if (!(nd >= best || nd < eps)) {
+                            best = nd;
+                            hit = static_cast<int>(s_queue[start + kk - base] & 0xFFFFFFu);
+                        }
+                    }
+                    wave_sync();
                 }
                 n_slots = 0;
             };
 
             // ---- 1. cull
             const ConstF clusters = (ConstF)reinterpret_cast<uintptr_t>(a.clusters);
-            const ConstU words = (ConstU)reinterpret_cast<uintptr_t>(a.words);
             const ConstF spheres = (ConstF)reinterpret_cast<uintptr_t>(a.spheres);
             const ConstF bary = (ConstF)reinterpret_cast<uintptr_t>(a.bary);
             for (int cl = 0; cl < a.n_clusters; ++cl) {
                 const ConstF cp = clusters + 8 * cl;
                 const bool pc = valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q);
                 if (!__any(pc)) continue;
-                const uint32_t w0 = ((ConstU)cp)[4], w1 = w0 + ((ConstU)cp)[5];
-                for (uint32_t w = w0; w < w1; ++w) {
-                    const ConstU wd = words + 4 * w;
-                    const uint32_t first = wd[0], count = wd[1], kind = wd[2], off = wd[3];
-                    uint32_t m = 0;
-                    if (kind == 0) {
-                        const ConstF sp = spheres + 4 * static_cast<size_t>(off);
-                        for (int o = 0; o < kChunk / kOctet; ++o) {
-                            const bool po = pc & sphere_keep(sp[4 * o], sp[4 * o + 1], sp[4 * o + 2], sp[4 * o + 3], q);
-                            if (!__any(po)) continue;
-                            const ConstF tp = sp + 4 * (kChunk / kOctet) + 4 * kOctet * o;
-                            uint32_t mo = 0;
+                const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
+                const int n_words = static_cast<int>((n_tri + kChunk - 1) / kChunk);
+                if (n_slots + n_words > kSlots) flush();
+                if (kind == 0) {
+                    // (a) every lane against the cluster's octet spheres (wave-uniform, records in SGPRs)
+                    uint32_t omask = 0;
+                    for (int w = 0; w < n_words; ++w) {
+                        const ConstF sp = spheres + 4 * (static_cast<size_t>(off) + 36u * w);
 #pragma unroll
-                            for (int k = 0; k < kOctet; ++k) {
-                                const bool pt = sphere_keep(tp[4 * k], tp[4 * k + 1], tp[4 * k + 2], tp[4 * k + 3], q);
-                                mo |= pt ? (1u << k) : 0u;
-                            }
-                            m |= (po ? mo : 0u) << (kOctet * o);
+                        for (int o = 0; o < 4; ++o) {
+                            const bool po = sphere_keep(sp[4 * o], sp[4 * o + 1], sp[4 * o + 2], sp[4 * o + 3], q);
+                            omask |= po ? (1u << (4 * w + o)) : 0u;
                         }
-                    } else {
-                        const ConstF bp = bary + 12 * static_cast<size_t>(off);
-                        for (uint32_t k0 = 0; k0 < count; k0 += 4) {   // records are padded to whole words
+                    }
+                    omask = pc ? omask : 0u;
+                    if (!__any(omask != 0)) continue;
+                    for (int w = 0; w < n_words; ++w) {
+                        s_cand[n_slots + w][lane] = 0;
+                        if (lane == 0) {
+                            const uint32_t left = n_tri - kChunk * w;
+                            s_first[n_slots + w] = first_tri + kChunk * w;
+                            s_live[n_slots + w] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                        }
+                    }
+                    // (b) the (lane, octet) pairs that survived, spread evenly over the lanes: 8 triangle spheres each
+                    const uint32_t mine = __builtin_popcount(omask);
+                    const uint32_t incl = wave_inclusive_scan(mine, lane);
+                    const uint32_t start = incl - mine;
+                    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                    uint32_t om = omask, k = 0;
+                    for (uint32_t base = 0; base < total; base += kQueue) {
+                        const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
+                        while (k < mine && start + k < base + kQueue) {
+                            const uint32_t b = __builtin_ctz(om);
+                            om &= om - 1;
+                            s_queue[start + k - base] = b | (static_cast<uint32_t>(lane) << 8);
+                            ++k;
+                        }
+                        wave_sync();
+                        for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
+                            ++w_octets;
+                            const uint32_t i = i0 + lane;
+                            if (i < n_in) {
+                                const uint32_t e = s_queue[i];
+                                const uint32_t src = e >> 8, b = e & 31u;
+                                Ray r;
+                                r.ox = s_ray[0][src]; r.oy = s_ray[1][src]; r.oz = s_ray[2][src];
+                                r.dx = s_ray[3][src]; r.dy = s_ray[4][src]; r.dz = s_ray[5][src];
+                                const float4 *tp = reinterpret_cast<const float4 *>(a.spheres) + off + 36u * (b >> 2) + 4u + 8u * (b & 3u);
+                                uint32_t m8 = 0;
+#pragma unroll
+                                for (int t8 = 0; t8 < kOctet; ++t8) {
+                                    const float4 sp = tp[t8];
+                                    m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << t8) : 0u;
+                                }
+                                if (m8) atomicOr(&s_cand[n_slots + (b >> 2)][src], m8 << (8u * (b & 3u)));
+                            }
+                        }
+                        wave_sync();
+                    }
+                    n_slots += n_words;
+                } else {
+                    // large triangles: barycentric cull, wave-uniform over the triangles
+                    for (int w = 0; w < n_words; ++w) {
+                        const uint32_t left = n_tri - kChunk * w;
+                        const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
+                        uint32_t m = 0;
+                        for (uint32_t k0 = 0; k0 < min(left, 32u); k0 += 4) {   // records are padded to whole words
 #pragma unroll
                             for (uint32_t j = 0; j < 4; ++j) {
                                 const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
@@ -297,16 +422,19 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
                             }
                         }
                         m = pc ? m : 0u;
-                    }
-                    m &= count >= 32u ? 0xFFFFFFFFu : ((1u << count) - 1u);   // padding records are never candidates
-                    if (__any(m != 0)) {
-                        cand[n_slots][tid] = make_uint2(m, first);
-                        ++n_slots;
-                        if (n_slots == kSlots) run_exact();
+                        if (__any(m != 0)) {
+                            s_cand[n_slots][lane] = m;
+                            if (lane == 0) {
+                                s_first[n_slots] = first_tri + kChunk * w;
+                                s_live[n_slots] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                            }
+                            ++n_slots;
+                        }
                     }
                 }
+                wave_sync();
             }
-            run_exact();
+            if (n_slots > 0) flush();
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
             if (valid) {
@@ -388,13 +516,18 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
         atomicAdd(&a.stats[2], static_cast<unsigned long long>(n_contrib));
         atomicAdd(&a.stats[3], static_cast<unsigned long long>(n_exact));
         atomicAdd(&a.stats[4], static_cast<unsigned long long>(n_miss));
+        if (lane == 0) {
+            atomicAdd(&a.stats[5], static_cast<unsigned long long>(w_segments));
+            atomicAdd(&a.stats[6], static_cast<unsigned long long>(w_octets));
+            atomicAdd(&a.stats[7], static_cast<unsigned long long>(w_exact_iters));
+        }
     }
 }
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     const int rows = args.row_end - args.row_begin;
     if (rows <= 0 || args.width <= 0) return hipSuccess;
-    const int blocks_y = (rows + 15) / 16;
+    const int blocks_y = (rows + 7) / 8;
     const unsigned grid = static_cast<unsigned>(args.blocks_x) * static_cast<unsigned>(blocks_y);
     hipLaunchKernelGGL(integrate_kernel, dim3(grid), dim3(kBlock), 0, stream, args);
     return hipGetLastError();

@@ -12,21 +12,20 @@ constexpr uint32_t kPhiloxKey1 = 0x50544831u;   // "PTH1": second Philox key wor
 
 struct RenderArgs {
     const ClusterDesc *clusters;   // cull hierarchy (pt_scene.hpp: CullTables), read through the scalar cache
-    const WordDesc *words;
     const SphereRec *spheres;
     const CullRec *bary;
     const ExactRec *exact;    // n_tri
     const MatRec *mats;
     float *sum, *sum2;        // row band, 3 floats per pixel
     int32_t *count;
-    unsigned long long *stats;   // 5 counters or nullptr
+    unsigned long long *stats;   // 8 counters or nullptr
     int32_t n_clusters, n_tri;
     int32_t width, height, row_begin, row_end;
     int32_t pass_begin, pass_count, mrr;
     float eps, error;
     uint32_t seed;
     float k1, k2, a_max, m0, t_guard;   // cull margins (pt_scene.hpp: CullConstants)
-    int32_t blocks_x;                   // ceil(width / 16)
+    int32_t blocks_x;                   // ceil(width / 8)
 };
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);

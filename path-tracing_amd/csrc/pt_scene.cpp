@@ -327,33 +327,40 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         const double reff = sphere_of(i, 1, tmp);
         large[i] = !(reff < 0.12 * r_max);
     }
-    // ---- words (<= 32 consecutive triangles of one class), clusters (<= 8 consecutive words of one class)
+    // ---- clusters: runs of up to 256 consecutive triangles of one class
     const SphereRec never = {{0, 0, 0}, -1.0e30f};
     int i = 0;
     while (i < T) {
         const bool lg = large[i];
         int n = 1;
-        while (i + n < T && n < kChunk && large[i + n] == lg) ++n;
-        WordDesc w;
-        w.first_tri = static_cast<uint32_t>(i);
-        w.count = static_cast<uint32_t>(n);
-        w.kind = lg ? 1u : 0u;
+        while (i + n < T && n < kChunk * kClusterWords && large[i + n] == lg) ++n;
+        ClusterDesc cd;
+        SphereRec cs;
+        sphere_of(i, n, cs);
+        cd.c[0] = cs.c[0]; cd.c[1] = cs.c[1]; cd.c[2] = cs.c[2]; cd.r2 = cs.r2;
+        cd.first_tri = static_cast<uint32_t>(i);
+        cd.n_tri = static_cast<uint32_t>(n);
+        cd.kind = lg ? 1u : 0u;
+        const int n_words = (n + kChunk - 1) / kChunk;
         if (!lg) {
-            w.data_off = static_cast<uint32_t>(out.spheres.size());
-            for (int o = 0; o < kChunk / kOctet; ++o) {
-                SphereRec sr = never;
-                const int f = i + o * kOctet, c = std::min(kOctet, i + n - f);
-                if (c > 0) sphere_of(f, c, sr);
-                out.spheres.push_back(sr);
-            }
-            for (int k = 0; k < kChunk; ++k) {
-                SphereRec sr = never;
-                if (k < n) sphere_of(i + k, 1, sr);
-                out.spheres.push_back(sr);
+            cd.data_off = static_cast<uint32_t>(out.spheres.size());
+            for (int w = 0; w < n_words; ++w) {
+                const int wf = i + w * kChunk, wn = std::min(kChunk, i + n - wf);
+                for (int o = 0; o < kChunk / kOctet; ++o) {
+                    SphereRec sr = never;
+                    const int f = wf + o * kOctet, c = std::min(kOctet, wf + wn - f);
+                    if (c > 0) sphere_of(f, c, sr);
+                    out.spheres.push_back(sr);
+                }
+                for (int k = 0; k < kChunk; ++k) {
+                    SphereRec sr = never;
+                    if (k < wn) sphere_of(wf + k, 1, sr);
+                    out.spheres.push_back(sr);
+                }
             }
         } else {
-            w.data_off = static_cast<uint32_t>(out.bary.size());
-            for (int k = 0; k < kChunk; ++k) {
+            cd.data_off = static_cast<uint32_t>(out.bary.size());
+            for (int k = 0; k < n_words * kChunk; ++k) {
                 CullRec c;
                 std::memset(&c, 0, sizeof c);
                 if (k < n) {
@@ -381,25 +388,8 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
                 out.bary.push_back(c);
             }
         }
-        out.words.push_back(w);
+        out.clusters.push_back(cd);
         i += n;
-    }
-    size_t wi = 0;
-    while (wi < out.words.size()) {
-        const uint32_t kind = out.words[wi].kind;
-        size_t n = 1;
-        while (wi + n < out.words.size() && n < static_cast<size_t>(kClusterWords) && out.words[wi + n].kind == kind) ++n;
-        ClusterDesc c;
-        std::memset(&c, 0, sizeof c);
-        c.first_word = static_cast<uint32_t>(wi);
-        c.n_words = static_cast<uint32_t>(n);
-        const int first = static_cast<int>(out.words[wi].first_tri);
-        const int last = static_cast<int>(out.words[wi + n - 1].first_tri + out.words[wi + n - 1].count);
-        SphereRec sr;
-        sphere_of(first, last - first, sr);
-        c.c[0] = sr.c[0]; c.c[1] = sr.c[1]; c.c[2] = sr.c[2]; c.r2 = sr.r2;
-        out.clusters.push_back(c);
-        wi += n;
     }
     // keep the tables non-empty and padded so that speculative wide scalar loads stay inside the allocation
     for (int k = 0; k < 16; ++k) out.spheres.push_back(never);

@@ -58,15 +58,14 @@ static const int kClusterWords = 8;   // words per cluster (256 triangles)
 struct SphereRec {
     float c[3], r2;
 };
-// One candidate-mask word = up to 32 consecutive triangles of one class.
-//   kind 0 (small triangles): data_off indexes SphereRec: 4 octet spheres, then 32 triangle spheres
-//   kind 1 (large triangles): data_off indexes CullRec (one barycentric cull record per triangle, padded to 32)
-struct WordDesc {
-    uint32_t first_tri, count, kind, data_off;
-};
+// A cluster = up to 256 consecutive triangles of one class, cut into words of 32 (one candidate-mask word each)
+// and, for small triangles, octets of 8.
+//   kind 0 (small triangles): data_off indexes SphereRec; word w of the cluster owns 36 records from
+//                             data_off + 36 w: its 4 octet spheres, then its 32 triangle spheres
+//   kind 1 (large triangles): data_off indexes CullRec; word w owns 32 barycentric cull records from data_off + 32 w
 struct ClusterDesc {
     float c[3], r2;
-    uint32_t first_word, n_words, pad0, pad1;
+    uint32_t first_tri, n_tri, kind, data_off;
 };
 
 // Margins of the barycentric cull test for one render call (depend on eps).
@@ -81,7 +80,6 @@ struct CullConstants {
 struct CullTables {
     std::vector<SphereRec> spheres;
     std::vector<CullRec> bary;
-    std::vector<WordDesc> words;
     std::vector<ClusterDesc> clusters;
     CullConstants cc;
     float eps = 0;
