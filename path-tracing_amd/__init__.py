@@ -14,7 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
+# PT_HIP_LIB selects another build of the same ABI (kernel-variant experiments); the default is the in-tree library.
+LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "lib", "libpt_hip.so")
 
 PT_OK = 0
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT_ERR_PARSE", 4: "PT_ERR_NO_DEVICE",

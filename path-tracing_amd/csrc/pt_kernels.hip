@@ -26,9 +26,12 @@ namespace pt {
 
 namespace {
 
+#ifndef PT_WAVES_PER_SIMD
+#define PT_WAVES_PER_SIMD 6
+#endif
 constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per workgroup (all LDS below is wave-private)
-constexpr int kSlots = 16;                // candidate-mask words (32 triangles each) parked per lane between cull and exact
-constexpr int kQueue = 256;               // work items per batch of the two lane-balanced queues
+constexpr int kSlots = 12;                // candidate-mask words (32 triangles each) parked per lane between cull and exact
+constexpr int kQueue = 128;               // work items per batch of the two lane-balanced queues
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -205,7 +208,7 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // ---------------------------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
     __shared__ uint32_t s_cand[kSlots][64];   // per lane: candidate bits of one 32-triangle word
     __shared__ uint32_t s_first[kSlots];      // index of the word's first triangle
     __shared__ uint32_t s_live[kSlots];       // bits of the word that are real triangles
@@ -220,32 +223,27 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
     const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
     const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
 
-    float sr = 0, sg = 0, sb = 0, qr = 0, qg = 0, qb = 0;
-    int cnt = 0;
-    if (in_image) {
-        sr = a.sum[3 * p]; sg = a.sum[3 * p + 1]; sb = a.sum[3 * p + 2];
-        qr = a.sum2[3 * p]; qg = a.sum2[3 * p + 1]; qb = a.sum2[3 * p + 2];
-        cnt = a.count[p];
-    }
+    // The accumulators stay in global memory: a pixel belongs to one lane, only ~1 % of the samples touch them
+    // (material.h:74-77), and seven fewer live VGPRs buy a wave per SIMD.  Adds still happen in pass order.
+    float *const acc_sum = a.sum + 3 * p;
+    float *const acc_sum2 = a.sum2 + 3 * p;
+    int32_t *const acc_count = a.count + p;
+    // statistics are wave-level (uniform) counts: they live in SGPRs
     uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_exact = 0, n_miss = 0;
-    uint32_t w_segments = 0, w_octets = 0, w_exact_iters = 0;   // wave-level (uniform) diagnostics
+    uint32_t w_segments = 0, w_octets = 0, w_exact_iters = 0;
 
     const int mrr = a.mrr;
     const float eps = a.eps;
-    // Cull margins live in VGPRs: a VALU instruction can name only one SGPR, so an SGPR-resident constant next to an
-    // SGPR-resident triangle coefficient would cost a v_mov per use.  The empty asm stops rematerialisation.
-    float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, t_guard = a.t_guard;
-    asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(t_guard));
 
     for (int pass = a.pass_begin; pass < a.pass_begin + a.pass_count; ++pass) {
         // Adaptive skip, main.cpp:118-125.
         bool skip = !in_image;
-        {
-            const float sc = static_cast<float>(cnt);
-            if (pass > 10 && sc > 0) {
-                const float mr = sr / sc, mg_ = sg / sc, mb = sb / sc;
-                const float dr = qr / sc - mr * mr, dg = qg / sc - mg_ * mg_, db = qb / sc - mb * mb;
-                if ((pass % 4) && dr < a.error && dg < a.error && db < a.error) skip = true;
+        if (pass > 10 && (pass % 4) && in_image) {
+            const float sc = static_cast<float>(*acc_count);
+            if (sc > 0) {
+                const float mr = acc_sum[0] / sc, mg_ = acc_sum[1] / sc, mb = acc_sum[2] / sc;
+                const float dr = acc_sum2[0] / sc - mr * mr, dg = acc_sum2[1] / sc - mg_ * mg_, db = acc_sum2[2] / sc - mb * mb;
+                if (dr < a.error && dg < a.error && db < a.error) skip = true;
             }
         }
         if (__all(skip)) continue;
@@ -265,14 +263,16 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
             q.dx = q.dx * inv; q.dy = q.dy * inv; q.dz = q.dz * inv;
             q.ox = 0.0f; q.oy = 0.0f; q.oz = -20.0f;
             depth = 0;
-            ++n_traced;
         } else {
             q.ox = q.oy = q.oz = 0.0f; q.dx = q.dy = 0.0f; q.dz = 1.0f;
         }
 
+        n_traced += __builtin_popcountll(__ballot(!skip));
+
         for (;;) {
             const bool valid = depth < mrr && (tr != 0.0f || tg != 0.0f || tb != 0.0f);   // Ray::IsValid, ray.h:52-54
             if (!__any(valid)) break;
+            n_segments += __builtin_popcountll(__ballot(valid));
 
             ++w_segments;
             float best = __builtin_inff();
@@ -322,9 +322,9 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
                             r.ox = s_ray[0][src]; r.oy = s_ray[1][src]; r.oz = s_ray[2][src];
                             r.dx = s_ray[3][src]; r.dy = s_ray[4][src]; r.dz = s_ray[5][src];
                             s_res[i] = exact_inside(a.exact + tri, r, eps);
-                            ++n_exact;
                         }
                     }
+                    n_exact += n_in;
                     wave_sync();
                     // (c) replay in triangle order (scene.cpp:116-120 with the stage-A test of triangles.h:51)
                     for (uint32_t kk = k_first; kk < k; ++kk) {
@@ -409,7 +409,11 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
                     }
                     n_slots += n_words;
                 } else {
-                    // large triangles: barycentric cull, wave-uniform over the triangles
+                    // large triangles: barycentric cull, wave-uniform over the triangles.
+                    // The margins go to VGPRs here: a VALU instruction can name only one SGPR, so an SGPR-resident
+                    // constant next to an SGPR-resident triangle coefficient would cost a v_mov per use.
+                    float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, t_guard = a.t_guard;
+                    asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(t_guard));
                     for (int w = 0; w < n_words; ++w) {
                         const uint32_t left = n_tri - kChunk * w;
                         const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
@@ -437,10 +441,10 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
             if (n_slots > 0) flush();
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
+            n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
+            bool contributed = false;
             if (valid) {
-                ++n_segments;
                 if (hit < 0) {
-                    ++n_miss;
                     depth = mrr;   // MakeInvalid
                 } else {
                     const ExactRec *__restrict__ rec = a.exact + hit;
@@ -469,10 +473,10 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
                     } else if (kind == 0) {   // emissive, material.h:68-79
                         if (!((q.dx * pl.x + q.dy * pl.y) + q.dz * pl.z > 0)) {
                             const float cr = tr * m0v.x, cg = tg * m0v.y, cb = tb * m0v.z;
-                            sr += cr; sg += cg; sb += cb;
-                            qr += cr * cr; qg += cg * cg; qb += cb * cb;
-                            ++cnt;
-                            ++n_contrib;
+                            acc_sum[0] += cr; acc_sum[1] += cg; acc_sum[2] += cb;
+                            acc_sum2[0] += cr * cr; acc_sum2[1] += cg * cg; acc_sum2[2] += cb * cb;
+                            *acc_count += 1;
+                            contributed = true;
                         }
                         depth = mrr;
                     } else if (kind == 1) {   // glossy, material.h:83-85
@@ -502,25 +506,19 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(const RenderArgs a) {
                     }
                 }
             }
+            n_contrib += __builtin_popcountll(__ballot(contributed));
         }
     }
 
-    if (in_image) {
-        a.sum[3 * p] = sr; a.sum[3 * p + 1] = sg; a.sum[3 * p + 2] = sb;
-        a.sum2[3 * p] = qr; a.sum2[3 * p + 1] = qg; a.sum2[3 * p + 2] = qb;
-        a.count[p] = cnt;
-    }
-    if (a.stats) {
+    if (a.stats && lane == 0) {
         atomicAdd(&a.stats[0], static_cast<unsigned long long>(n_traced));
         atomicAdd(&a.stats[1], static_cast<unsigned long long>(n_segments));
         atomicAdd(&a.stats[2], static_cast<unsigned long long>(n_contrib));
         atomicAdd(&a.stats[3], static_cast<unsigned long long>(n_exact));
         atomicAdd(&a.stats[4], static_cast<unsigned long long>(n_miss));
-        if (lane == 0) {
-            atomicAdd(&a.stats[5], static_cast<unsigned long long>(w_segments));
-            atomicAdd(&a.stats[6], static_cast<unsigned long long>(w_octets));
-            atomicAdd(&a.stats[7], static_cast<unsigned long long>(w_exact_iters));
-        }
+        atomicAdd(&a.stats[5], static_cast<unsigned long long>(w_segments));
+        atomicAdd(&a.stats[6], static_cast<unsigned long long>(w_octets));
+        atomicAdd(&a.stats[7], static_cast<unsigned long long>(w_exact_iters));
     }
 }
 
