@@ -106,6 +106,13 @@ int pt_render_device(pt_scene *scene, const pt_render_params *params, float *d_s
 int pt_render_host(pt_scene *scene, const pt_render_params *params, float *sum, float *sum2, int32_t *count,
                    pt_render_stats *stats);
 
+/* Closest hit for caller-supplied rays: the triangle loop of Scene::TraceRay (scene.cpp:114-120) on the GPU.
+ * origins/directions: 3 floats per ray (HOST buffers); directions must already be normalised the way Ray's
+ * constructor does it (ray.h:23) -- the culling hierarchy assumes unit directions.  hit_index[i] = index of the
+ * accepted triangle with the smallest distance (lowest index on ties) or -1, hit_t[i] = that distance (+inf on a miss). */
+int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps,
+                       int32_t *hit_index, float *hit_t);
+
 /* ---- resolve + image output (host side, as in the reference) --------------------------------------- */
 
 /* main.cpp:162-201: per-pixel mean, gamma tonemap *255, float->uint8 truncation (bitmap_image.hpp:194-206),

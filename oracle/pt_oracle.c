@@ -446,6 +446,32 @@ int orc_closest_hit(const orc_scene *s, const float *o, const float *d, float ep
     return cur;
 }
 
+/* 1 if some triangle's plane evaluation is not a finite number for this ray (0/0: the ray lies exactly in the stored
+ * plane).  The reference then accepts that triangle whatever the geometry (every comparison with NaN is false). */
+static int ray_sees_nan(const orc_scene *s, const float *o, const float *d) {
+    for (int i = 0; i < s->n_tri; ++i) {
+        const float *p = s->tri[i].plane;
+        const float sd = d[0] * p[0] + d[1] * p[1] + d[2] * p[2];
+        const float nd = -(o[0] * p[0] + o[1] * p[1] + o[2] * p[2] + p[3]) / sd;
+        if (nd != nd) return 1;
+    }
+    return 0;
+}
+
+void orc_closest_hit_batch(const orc_scene *s, int n, const float *o, const float *d, float eps, int *idx, float *t,
+                           unsigned char *nan_seen, int threads) {
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+#pragma omp parallel for schedule(static, 256) num_threads(threads)
+    for (int i = 0; i < n; ++i) {
+        idx[i] = orc_closest_hit(s, o + 3 * (size_t)i, d + 3 * (size_t)i, eps, t + i);
+        if (nan_seen) nan_seen[i] = (unsigned char)ray_sees_nan(s, o + 3 * (size_t)i, d + 3 * (size_t)i);
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* Path state and shading                                               */
 /* ------------------------------------------------------------------ */

@@ -23,7 +23,8 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT
 
 # every symbol include/pt_hip.h declares
 ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
-               "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_resolve",
+               "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_trace_rays_host",
+               "pt_resolve",
                "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
 
 
@@ -76,6 +77,7 @@ def lib():
         L.pt_scene_destroy.restype = None
         L.pt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, C.POINTER(RenderStats)]
         L.pt_render_host.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.POINTER(RenderStats)]
+        L.pt_trace_rays_host.argtypes = [vp, C.c_int32, fp, fp, C.c_float, ip, fp]
         L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
         L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.pt_last_error.restype = C.c_char_p
@@ -151,6 +153,15 @@ class Scene:
         st = RenderStats()
         _check(lib().pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None))
         return s, s2, c, st.as_dict()
+
+    def trace_rays(self, origins, directions, eps=1e-4):
+        """Closest hit per ray (scene.cpp:114-120).  directions must be unit length (normalised as ray.h:23 does)."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        idx = np.full(len(o), -2, np.int32)
+        t = np.zeros(len(o), np.float32)
+        _check(lib().pt_trace_rays_host(self._h, len(o), _fp(o), _fp(d), eps, _ip(idx), _fp(t)))
+        return idx, t
 
     def render_device(self, params, d_sum, d_sum2, d_count, stream=None, want_stats=False):
         """d_* are raw device pointers (ints), e.g. torch tensors' data_ptr(); stream is a hipStream_t value."""

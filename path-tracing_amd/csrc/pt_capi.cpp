@@ -265,6 +265,50 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     return PT_OK;
 }
 
+int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps,
+                       int32_t *hit_index, float *hit_t) {
+    if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
+    if (scene->device < 0) return fail(PT_ERR_NO_DEVICE, "scene was created without a device (device < 0)");
+    if (n_rays < 0 || (n_rays > 0 && (!origins || !directions || !hit_index || !hit_t)))
+        return fail(PT_ERR_INVALID_ARGUMENT, "null ray buffer or negative count");
+    if (n_rays == 0) return PT_OK;
+    PT_HIP_TRY(hipSetDevice(scene->device));
+    const int crc = ensure_cull(scene, eps);
+    if (crc != PT_OK) return crc;
+    const pt::CullConstants cc = scene->cull.host.cc;
+    pt::RenderArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.clusters = scene->cull.clusters;
+    a.spheres = scene->cull.spheres;
+    a.bary = scene->cull.bary;
+    a.exact = scene->d_exact;
+    a.mats = scene->d_mats;
+    a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
+    a.n_tri = scene->host.n_tri();
+    a.eps = eps;
+    a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    int32_t *d_i = nullptr;
+    const size_t n = static_cast<size_t>(n_rays);
+    int result = PT_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_o), n * 12);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_d), n * 12);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_t), n * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_i), n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, directions, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pt::launch_trace_rays(a, d_o, d_d, n_rays, d_i, d_t, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(hit_index, d_i, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hit_t, d_t, n * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) result = hip_fail(e, "pt_trace_rays_host");
+    if (d_o) (void)hipFree(d_o);
+    if (d_d) (void)hipFree(d_d);
+    if (d_t) (void)hipFree(d_t);
+    if (d_i) (void)hipFree(d_i);
+    return result;
+}
+
 int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float *sum2, int32_t *count,
                    pt_render_stats *stats) {
     const int rc = check_params(scene, p);

@@ -206,15 +206,195 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
+// Closest hit of every lane's ray: Scene::TraceRay's loop (scene.cpp:114-120) for one wave.  Wave-uniform control
+// flow: all 64 lanes must call it together; lanes with valid == false take part in the shared work only.
+// ---------------------------------------------------------------------------------------------------------------
+struct WaveLds {
+    uint32_t cand[kSlots][64];   // per lane: candidate bits of one 32-triangle word
+    uint32_t first[kSlots];      // index of the word's first triangle
+    uint32_t live[kSlots];       // bits of the word that are real triangles
+    float ray[6][64];            // this segment's rays, readable by every lane
+    uint32_t queue[kQueue];      // work items: (octet | lane << 8) or (triangle | lane << 24)
+    float res[kQueue];           // per (ray, triangle) item: t if inside, -inf otherwise
+};
+struct WaveStats {
+    uint32_t n_exact = 0, w_segments = 0, w_octets = 0, w_exact_iters = 0;   // wave-uniform, live in SGPRs
+};
+
+__device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, const Ray &q, bool valid, int lane,
+                                            float eps, float &best, int &hit, WaveStats &st) {
+    ++st.w_segments;
+    best = __builtin_inff();
+    hit = -1;
+    int n_slots = 0;   // wave-uniform
+
+    // every lane's ray, for the lane-balanced phases
+    lds.ray[0][lane] = q.ox; lds.ray[1][lane] = q.oy; lds.ray[2][lane] = q.oz;
+    lds.ray[3][lane] = q.dx; lds.ray[4][lane] = q.dy; lds.ray[5][lane] = q.dz;
+
+    // ---- 2. exact.  The candidates parked in lds.cand are spread evenly over the lanes (a lane works on other
+    // lanes' rays), each (ray, triangle) pair yields t and the outcome of stages B-D of Triangle::Intersect,
+    // and every lane then replays its own pairs in triangle order with the reference's running `distance`
+    // (stage A, triangles.h:51), so the closest-hit choice is the reference's, ties and NaNs included.
+    auto flush = [&]() {
+        uint32_t mine = 0;
+        for (int sl = 0; sl < n_slots; ++sl) {
+            const uint32_t m = lds.cand[sl][lane] & lds.live[sl];
+            lds.cand[sl][lane] = m;
+            mine += __builtin_popcount(m);
+        }
+        const uint32_t incl = wave_inclusive_scan(mine, lane);
+        const uint32_t start = incl - mine;
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        int c = -1;            // cursor over this lane's candidates
+        uint32_t m = 0, k = 0;
+        for (uint32_t base = 0; base < total; base += kQueue) {
+            const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
+            // (a) publish this lane's pairs that fall into the batch, in triangle order
+            const uint32_t k_first = k;
+            while (k < mine && start + k < base + kQueue) {
+                while (m == 0) { ++c; m = lds.cand[c][lane]; }
+                const uint32_t j = __builtin_ctz(m);
+                m &= m - 1;
+                lds.queue[start + k - base] = (lds.first[c] + j) | (static_cast<uint32_t>(lane) << 24);
+                ++k;
+            }
+            wave_sync();
+            // (b) balanced: lane l takes pairs l, l+64, ...
+            for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
+                ++st.w_exact_iters;
+                const uint32_t i = i0 + lane;
+                if (i < n_in) {
+                    const uint32_t e = lds.queue[i];
+                    const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
+                    Ray r;
+                    r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                    r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                    lds.res[i] = exact_inside(a.exact + tri, r, eps);
+                }
+            }
+            st.n_exact += n_in;
+            wave_sync();
+            // (c) replay in triangle order (scene.cpp:116-120 with the stage-A test of triangles.h:51)
+            for (uint32_t kk = k_first; kk < k; ++kk) {
+                const float nd = lds.res[start + kk - base];
+                if (!(nd >= best || nd < eps)) {
+                    best = nd;
+                    hit = static_cast<int>(lds.queue[start + kk - base] & 0xFFFFFFu);
+                }
+            }
+            wave_sync();
+        }
+        n_slots = 0;
+    };
+
+    // ---- 1. cull
+    const ConstF clusters = (ConstF)reinterpret_cast<uintptr_t>(a.clusters);
+    const ConstF spheres = (ConstF)reinterpret_cast<uintptr_t>(a.spheres);
+    const ConstF bary = (ConstF)reinterpret_cast<uintptr_t>(a.bary);
+    for (int cl = 0; cl < a.n_clusters; ++cl) {
+        const ConstF cp = clusters + 8 * cl;
+        const bool pc = valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q);
+        if (!__any(pc)) continue;
+        const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
+        const int n_words = static_cast<int>((n_tri + kChunk - 1) / kChunk);
+        if (n_slots + n_words > kSlots) flush();
+        if (kind == 0) {
+            // (a) every lane against the cluster's octet spheres (wave-uniform, records in SGPRs)
+            uint32_t omask = 0;
+            for (int w = 0; w < n_words; ++w) {
+                const ConstF sp = spheres + 4 * (static_cast<size_t>(off) + 36u * w);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const bool po = sphere_keep(sp[4 * o], sp[4 * o + 1], sp[4 * o + 2], sp[4 * o + 3], q);
+                    omask |= po ? (1u << (4 * w + o)) : 0u;
+                }
+            }
+            omask = pc ? omask : 0u;
+            if (!__any(omask != 0)) continue;
+            for (int w = 0; w < n_words; ++w) {
+                lds.cand[n_slots + w][lane] = 0;
+                if (lane == 0) {
+                    const uint32_t left = n_tri - kChunk * w;
+                    lds.first[n_slots + w] = first_tri + kChunk * w;
+                    lds.live[n_slots + w] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                }
+            }
+            // (b) the (lane, octet) pairs that survived, spread evenly over the lanes: 8 triangle spheres each
+            const uint32_t mine = __builtin_popcount(omask);
+            const uint32_t incl = wave_inclusive_scan(mine, lane);
+            const uint32_t start = incl - mine;
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            uint32_t om = omask, k = 0;
+            for (uint32_t base = 0; base < total; base += kQueue) {
+                const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
+                while (k < mine && start + k < base + kQueue) {
+                    const uint32_t b = __builtin_ctz(om);
+                    om &= om - 1;
+                    lds.queue[start + k - base] = b | (static_cast<uint32_t>(lane) << 8);
+                    ++k;
+                }
+                wave_sync();
+                for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
+                    ++st.w_octets;
+                    const uint32_t i = i0 + lane;
+                    if (i < n_in) {
+                        const uint32_t e = lds.queue[i];
+                        const uint32_t src = e >> 8, b = e & 31u;
+                        Ray r;
+                        r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                        r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                        const float4 *tp = reinterpret_cast<const float4 *>(a.spheres) + off + 36u * (b >> 2) + 4u + 8u * (b & 3u);
+                        uint32_t m8 = 0;
+#pragma unroll
+                        for (int t8 = 0; t8 < kOctet; ++t8) {
+                            const float4 sp = tp[t8];
+                            m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << t8) : 0u;
+                        }
+                        if (m8) atomicOr(&lds.cand[n_slots + (b >> 2)][src], m8 << (8u * (b & 3u)));
+                    }
+                }
+                wave_sync();
+            }
+            n_slots += n_words;
+        } else {
+            // large triangles: barycentric cull, wave-uniform over the triangles.
+            // The margins go to VGPRs here: a VALU instruction can name only one SGPR, so an SGPR-resident
+            // constant next to an SGPR-resident triangle coefficient would cost a v_mov per use.
+            float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, t_guard = a.t_guard;
+            asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(t_guard));
+            for (int w = 0; w < n_words; ++w) {
+                const uint32_t left = n_tri - kChunk * w;
+                const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
+                uint32_t m = 0;
+                for (uint32_t k0 = 0; k0 < min(left, 32u); k0 += 4) {   // records are padded to whole words
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
+                        m |= rej ? 0u : (1u << (k0 + j));
+                    }
+                }
+                m = pc ? m : 0u;
+                if (__any(m != 0)) {
+                    lds.cand[n_slots][lane] = m;
+                    if (lane == 0) {
+                        lds.first[n_slots] = first_tri + kChunk * w;
+                        lds.live[n_slots] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                    }
+                    ++n_slots;
+                }
+            }
+        }
+        wave_sync();
+    }
+    if (n_slots > 0) flush();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
-    __shared__ uint32_t s_cand[kSlots][64];   // per lane: candidate bits of one 32-triangle word
-    __shared__ uint32_t s_first[kSlots];      // index of the word's first triangle
-    __shared__ uint32_t s_live[kSlots];       // bits of the word that are real triangles
-    __shared__ float s_ray[6][64];            // this segment's rays, readable by every lane
-    __shared__ uint32_t s_queue[kQueue];      // work items: (octet | lane << 8) or (triangle | lane << 24)
-    __shared__ float s_res[kQueue];           // per (ray, triangle) item: t if inside, -inf otherwise
+    __shared__ WaveLds lds;   // one wave per workgroup: everything in it is wave-private
 
     const int lane = threadIdx.x;
     const int x = (blockIdx.x % a.blocks_x) * 8 + (lane & 7);
@@ -229,8 +409,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
     float *const acc_sum2 = a.sum2 + 3 * p;
     int32_t *const acc_count = a.count + p;
     // statistics are wave-level (uniform) counts: they live in SGPRs
-    uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_exact = 0, n_miss = 0;
-    uint32_t w_segments = 0, w_octets = 0, w_exact_iters = 0;
+    uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_miss = 0;
+    WaveStats wst;
 
     const int mrr = a.mrr;
     const float eps = a.eps;
@@ -274,171 +454,9 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
             if (!__any(valid)) break;
             n_segments += __builtin_popcountll(__ballot(valid));
 
-            ++w_segments;
-            float best = __builtin_inff();
-            int hit = -1;
-            int n_slots = 0;   // wave-uniform
-
-            // every lane's ray, for the lane-balanced phases
-            s_ray[0][lane] = q.ox; s_ray[1][lane] = q.oy; s_ray[2][lane] = q.oz;
-            s_ray[3][lane] = q.dx; s_ray[4][lane] = q.dy; s_ray[5][lane] = q.dz;
-
-            // ---- 2. exact.  The candidates parked in s_cand are spread evenly over the lanes (a lane works on other
-            // lanes' rays), each (ray, triangle) pair yields t and the outcome of stages B-D of Triangle::Intersect,
-            // and every lane then replays its own pairs in triangle order with the reference's running `distance`
-            // (stage A, triangles.h:51), so the closest-hit choice is the reference's, ties and NaNs included.
-            auto flush = [&]() {
-                uint32_t mine = 0;
-                for (int sl = 0; sl < n_slots; ++sl) {
-                    const uint32_t m = s_cand[sl][lane] & s_live[sl];
-                    s_cand[sl][lane] = m;
-                    mine += __builtin_popcount(m);
-                }
-                const uint32_t incl = wave_inclusive_scan(mine, lane);
-                const uint32_t start = incl - mine;
-                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-                int c = -1;            // cursor over this lane's candidates
-                uint32_t m = 0, k = 0;
-                for (uint32_t base = 0; base < total; base += kQueue) {
-                    const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
-                    // (a) publish this lane's pairs that fall into the batch, in triangle order
-                    const uint32_t k_first = k;
-                    while (k < mine && start + k < base + kQueue) {
-                        while (m == 0) { ++c; m = s_cand[c][lane]; }
-                        const uint32_t j = __builtin_ctz(m);
-                        m &= m - 1;
-                        s_queue[start + k - base] = (s_first[c] + j) | (static_cast<uint32_t>(lane) << 24);
-                        ++k;
-                    }
-                    wave_sync();
-                    // (b) balanced: lane l takes pairs l, l+64, ...
-                    for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
-                        ++w_exact_iters;
-                        const uint32_t i = i0 + lane;
-                        if (i < n_in) {
-                            const uint32_t e = s_queue[i];
-                            const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
-                            Ray r;
-                            r.ox = s_ray[0][src]; r.oy = s_ray[1][src]; r.oz = s_ray[2][src];
-                            r.dx = s_ray[3][src]; r.dy = s_ray[4][src]; r.dz = s_ray[5][src];
-                            s_res[i] = exact_inside(a.exact + tri, r, eps);
-                        }
-                    }
-                    n_exact += n_in;
-                    wave_sync();
-                    // (c) replay in triangle order (scene.cpp:116-120 with the stage-A test of triangles.h:51)
-                    for (uint32_t kk = k_first; kk < k; ++kk) {
-                        const float nd = s_res[start + kk - base];
-                        if (!(nd >= best || nd < eps)) {
-                            best = nd;
-                            hit = static_cast<int>(s_queue[start + kk - base] & 0xFFFFFFu);
-                        }
-                    }
-                    wave_sync();
-                }
-                n_slots = 0;
-            };
-
-            // ---- 1. cull
-            const ConstF clusters = (ConstF)reinterpret_cast<uintptr_t>(a.clusters);
-            const ConstF spheres = (ConstF)reinterpret_cast<uintptr_t>(a.spheres);
-            const ConstF bary = (ConstF)reinterpret_cast<uintptr_t>(a.bary);
-            for (int cl = 0; cl < a.n_clusters; ++cl) {
-                const ConstF cp = clusters + 8 * cl;
-                const bool pc = valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q);
-                if (!__any(pc)) continue;
-                const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
-                const int n_words = static_cast<int>((n_tri + kChunk - 1) / kChunk);
-                if (n_slots + n_words > kSlots) flush();
-                if (kind == 0) {
-                    // (a) every lane against the cluster's octet spheres (wave-uniform, records in SGPRs)
-                    uint32_t omask = 0;
-                    for (int w = 0; w < n_words; ++w) {
-                        const ConstF sp = spheres + 4 * (static_cast<size_t>(off) + 36u * w);
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) {
-                            const bool po = sphere_keep(sp[4 * o], sp[4 * o + 1], sp[4 * o + 2], sp[4 * o + 3], q);
-                            omask |= po ? (1u << (4 * w + o)) : 0u;
-                        }
-                    }
-                    omask = pc ? omask : 0u;
-                    if (!__any(omask != 0)) continue;
-                    for (int w = 0; w < n_words; ++w) {
-                        s_cand[n_slots + w][lane] = 0;
-                        if (lane == 0) {
-                            const uint32_t left = n_tri - kChunk * w;
-                            s_first[n_slots + w] = first_tri + kChunk * w;
-                            s_live[n_slots + w] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
-                        }
-                    }
-                    // (b) the (lane, octet) pairs that survived, spread evenly over the lanes: 8 triangle spheres each
-                    const uint32_t mine = __builtin_popcount(omask);
-                    const uint32_t incl = wave_inclusive_scan(mine, lane);
-                    const uint32_t start = incl - mine;
-                    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-                    uint32_t om = omask, k = 0;
-                    for (uint32_t base = 0; base < total; base += kQueue) {
-                        const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
-                        while (k < mine && start + k < base + kQueue) {
-                            const uint32_t b = __builtin_ctz(om);
-                            om &= om - 1;
-                            s_queue[start + k - base] = b | (static_cast<uint32_t>(lane) << 8);
-                            ++k;
-                        }
-                        wave_sync();
-                        for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
-                            ++w_octets;
-                            const uint32_t i = i0 + lane;
-                            if (i < n_in) {
-                                const uint32_t e = s_queue[i];
-                                const uint32_t src = e >> 8, b = e & 31u;
-                                Ray r;
-                                r.ox = s_ray[0][src]; r.oy = s_ray[1][src]; r.oz = s_ray[2][src];
-                                r.dx = s_ray[3][src]; r.dy = s_ray[4][src]; r.dz = s_ray[5][src];
-                                const float4 *tp = reinterpret_cast<const float4 *>(a.spheres) + off + 36u * (b >> 2) + 4u + 8u * (b & 3u);
-                                uint32_t m8 = 0;
-#pragma unroll
-                                for (int t8 = 0; t8 < kOctet; ++t8) {
-                                    const float4 sp = tp[t8];
-                                    m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << t8) : 0u;
-                                }
-                                if (m8) atomicOr(&s_cand[n_slots + (b >> 2)][src], m8 << (8u * (b & 3u)));
-                            }
-                        }
-                        wave_sync();
-                    }
-                    n_slots += n_words;
-                } else {
-                    // large triangles: barycentric cull, wave-uniform over the triangles.
-                    // The margins go to VGPRs here: a VALU instruction can name only one SGPR, so an SGPR-resident
-                    // constant next to an SGPR-resident triangle coefficient would cost a v_mov per use.
-                    float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, t_guard = a.t_guard;
-                    asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(t_guard));
-                    for (int w = 0; w < n_words; ++w) {
-                        const uint32_t left = n_tri - kChunk * w;
-                        const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
-                        uint32_t m = 0;
-                        for (uint32_t k0 = 0; k0 < min(left, 32u); k0 += 4) {   // records are padded to whole words
-#pragma unroll
-                            for (uint32_t j = 0; j < 4; ++j) {
-                                const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
-                                m |= rej ? 0u : (1u << (k0 + j));
-                            }
-                        }
-                        m = pc ? m : 0u;
-                        if (__any(m != 0)) {
-                            s_cand[n_slots][lane] = m;
-                            if (lane == 0) {
-                                s_first[n_slots] = first_tri + kChunk * w;
-                                s_live[n_slots] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
-                            }
-                            ++n_slots;
-                        }
-                    }
-                }
-                wave_sync();
-            }
-            if (n_slots > 0) flush();
+            float best;
+            int hit;
+            closest_hit(a, lds, q, valid, lane, eps, best, hit, wst);
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
             n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
@@ -514,12 +532,45 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
         atomicAdd(&a.stats[0], static_cast<unsigned long long>(n_traced));
         atomicAdd(&a.stats[1], static_cast<unsigned long long>(n_segments));
         atomicAdd(&a.stats[2], static_cast<unsigned long long>(n_contrib));
-        atomicAdd(&a.stats[3], static_cast<unsigned long long>(n_exact));
+        atomicAdd(&a.stats[3], static_cast<unsigned long long>(wst.n_exact));
         atomicAdd(&a.stats[4], static_cast<unsigned long long>(n_miss));
-        atomicAdd(&a.stats[5], static_cast<unsigned long long>(w_segments));
-        atomicAdd(&a.stats[6], static_cast<unsigned long long>(w_octets));
-        atomicAdd(&a.stats[7], static_cast<unsigned long long>(w_exact_iters));
+        atomicAdd(&a.stats[5], static_cast<unsigned long long>(wst.w_segments));
+        atomicAdd(&a.stats[6], static_cast<unsigned long long>(wst.w_octets));
+        atomicAdd(&a.stats[7], static_cast<unsigned long long>(wst.w_exact_iters));
     }
+}
+
+// Closest hit for caller-supplied rays (the intersection half of Scene::TraceRay, scene.cpp:114-120).
+__global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void trace_rays_kernel(const RenderArgs a, const float *__restrict__ origins,
+                                                                              const float *__restrict__ directions, int n_rays,
+                                                                              int32_t *__restrict__ hit_index, float *__restrict__ hit_t) {
+    __shared__ WaveLds lds;
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * kBlock + lane;
+    const bool valid = i < n_rays;
+    Ray q;
+    q.ox = q.oy = q.oz = 0.0f; q.dx = q.dy = 0.0f; q.dz = 1.0f;
+    if (valid) {
+        q.ox = origins[3 * i]; q.oy = origins[3 * i + 1]; q.oz = origins[3 * i + 2];
+        q.dx = directions[3 * i]; q.dy = directions[3 * i + 1]; q.dz = directions[3 * i + 2];
+    }
+    float best;
+    int hit;
+    WaveStats st;
+    closest_hit(a, lds, q, valid, lane, a.eps, best, hit, st);
+    if (valid) {
+        hit_index[i] = hit;
+        hit_t[i] = best;
+    }
+}
+
+hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, const float *d_directions, int n_rays,
+                             int32_t *d_hit_index, float *d_hit_t, hipStream_t stream) {
+    if (n_rays <= 0) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((n_rays + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(kBlock), 0, stream, args, d_origins, d_directions, n_rays,
+                       d_hit_index, d_hit_t);
+    return hipGetLastError();
 }
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {

@@ -29,5 +29,7 @@ struct RenderArgs {
 };
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);
+hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, const float *d_directions, int n_rays,
+                             int32_t *d_hit_index, float *d_hit_t, hipStream_t stream);
 
 }  // namespace pt

@@ -59,6 +59,7 @@ def lib():
         L.orc_write_bmp.restype = C.c_size_t
         L.orc_write_bmp.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
         L.orc_closest_hit.argtypes = [vp, fp, fp, C.c_float, fp]
+        L.orc_closest_hit_batch.argtypes = [vp, C.c_int, fp, fp, C.c_float, ip, fp, C.POINTER(C.c_ubyte), C.c_int]
         L.orc_probe_minstd.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32), fp, C.POINTER(C.c_double)]
         L.orc_probe_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_probe_unit_float.restype = C.c_float
@@ -123,6 +124,16 @@ class Scene:
         t = C.c_float()
         i = lib().orc_closest_hit(self.h, _fp(o), _fp(d), eps, C.byref(t))
         return i, t.value
+
+    def closest_hits(self, origins, directions, eps=1e-4, threads=0):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        idx = np.zeros(len(o), np.int32)
+        t = np.zeros(len(o), np.float32)
+        nan_seen = np.zeros(len(o), np.uint8)
+        lib().orc_closest_hit_batch(self.h, len(o), _fp(o), _fp(d), eps, _ip(idx), _fp(t),
+                                    nan_seen.ctypes.data_as(C.POINTER(C.c_ubyte)), threads)
+        return idx, t, nan_seen.astype(bool)
 
     def __del__(self):
         try:

@@ -115,3 +115,54 @@ def test_synthetic_scene_with_all_material_kinds(gpu_scene):
     o = O.Scene.load(d, "b.obj")
     st, rst = _compare(g, o, 48, 32, 12, 8)
     assert st["contributing"] > 100
+
+
+# ---- large scenes: many clusters, several flushes of the candidate slots, several batches of the work queues ----
+def _replicated(tmp, instances):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_replicated_scene as M
+    d = str(tmp) + "/"
+    name = f"TorX{instances}.obj"
+    n = M.generate(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models"), d, name, instances)
+    return d, name, n
+
+
+@pytest.mark.parametrize("instances,W,H,spp", [(8, 64, 48, 6), (64, 56, 40, 3)])
+def test_replicated_scene_bit_exact(tmp_path, instances, W, H, spp):
+    d, name, n = _replicated(tmp_path, instances)      # BASELINE config 5 geometry (x64 -> 16 398 triangles)
+    g = pt.Scene.load_obj(d, name, device=0)
+    o = O.Scene.load(d, name)
+    assert g.counts()[0] == n == o.n_tri
+    st, rst = _compare(g, o, W, H, spp, 8)
+    assert st["exact_tests"] < 0.01 * st["segments"] * n
+
+
+def test_many_candidates_per_ray(tmp_path):
+    # a deep stack of large coplanar-ish sheets in front of the camera: every ray has dozens of candidate triangles,
+    # so the (ray, triangle) queue needs several batches and the slots several flushes
+    lines = ["mtllib s.mtl"]
+    open(str(tmp_path / "s.mtl"), "w").write("newmtl 0\nKe 1 1 1\nKd 1 1 1\nnewmtl 1\nNs 200\nKs 0.8 0.8 0.8\nKd 0.6 0.6 0.6\n")
+    nv = 0
+    k = 0
+    for layer in range(90):
+        z = -5.0 + 0.11 * layer
+        s = 9.0
+        lines += [f"v {-s} {-s} {z}", f"v {s} {-s} {z}", f"v {s} {s} {z}", f"v {-s} {s} {z}"]
+        lines += [f"usemtl {1 if layer % 7 else 0}", f"f {nv+1} {nv+2} {nv+3}", f"f {nv+1} {nv+3} {nv+4}"]
+        nv += 4
+    # plus a cloud of small triangles so that sphere clusters exist too
+    rng = np.random.default_rng(11)
+    for t in range(700):
+        p = rng.uniform(-6, 6, 3) + [0, 0, -9]
+        q = p + rng.uniform(-0.4, 0.4, 3)
+        r = p + rng.uniform(-0.4, 0.4, 3)
+        lines += ["v %f %f %f" % tuple(p), "v %f %f %f" % tuple(q), "v %f %f %f" % tuple(r), f"usemtl {t % 2}",
+                  f"f {nv+1} {nv+2} {nv+3}"]
+        nv += 3
+    open(str(tmp_path / "s.obj"), "w").write("\n".join(lines) + "\n")
+    d = str(tmp_path) + "/"
+    g = pt.Scene.load_obj(d, "s.obj", device=0)
+    o = O.Scene.load(d, "s.obj")
+    st, rst = _compare(g, o, 40, 32, 8, 8)
+    assert st["exact_tests"] > 20 * st["segments"]      # really many candidates per ray

@@ -1,0 +1,107 @@
+"""Closest-hit parity on explicit rays: the GPU's cull hierarchy + exact test against the oracle's brute-force loop
+(scene.cpp:114-120), bit for bit, on rays that ordinary path sampling rarely produces: grazing, edge-on, vertex-on,
+axis-aligned, starting on surfaces, pointing away."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pt = importlib.import_module("path-tracing_amd")
+pytestmark = pytest.mark.gpu
+
+
+def _normalise(d):
+    """Ray's constructor (ray.h:23): v * (1 / sqrt((x*x + y*y) + z*z)) in float32."""
+    d = np.ascontiguousarray(d, np.float32)
+    inv = np.float32(1.0) / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
+    return (d * inv[:, None]).astype(np.float32)
+
+
+def _adversarial_rays(tri, rng, n):
+    T = len(tri)
+    v = tri[:, 4:13].reshape(T, 3, 3).astype(np.float64)
+    nrm = tri[:, 0:3].astype(np.float64)
+    O_, D_ = [], []
+    # (1) random interior origins, random directions
+    o = rng.uniform([-9.9, -9.9, -20.9], [9.9, 9.9, 9.9], (n, 3))
+    d = rng.normal(size=(n, 3))
+    O_.append(o); D_.append(d)
+    # (2) from a surface point (+eps*N like the lobes do) towards a point on another triangle's EDGE or VERTEX
+    a, b = rng.integers(0, T, n), rng.integers(0, T, n)
+    w = rng.dirichlet([1, 1, 1], n)
+    src = (v[a] * w[:, :, None]).sum(1) + nrm[a] * 1e-4
+    e = rng.random((n, 1))
+    kind = rng.integers(0, 3, n)
+    tgt = np.where((kind == 0)[:, None], v[b, 0], np.where((kind == 1)[:, None], v[b, 0] * e + v[b, 1] * (1 - e),
+                                                           v[b, 1] * e + v[b, 2] * (1 - e)))
+    O_.append(src); D_.append(tgt - src)
+    # (3) grazing: direction in the plane of a triangle, tilted by a tiny angle, from just above that plane
+    a = rng.integers(0, T, n)
+    tang = v[a, 1] - v[a, 0]
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True) + 1e-30
+    tilt = rng.choice([0.0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3], n)[:, None]
+    src = (v[a] * w[:, :, None]).sum(1) + nrm[a] * rng.choice([0.0, 1e-4, -1e-4, 1e-2], n)[:, None] - tang * rng.uniform(0, 5, (n, 1))
+    O_.append(src); D_.append(tang + tilt * nrm[a])
+    # (4) axis-aligned directions and origins on lattice points (exact zeros in products)
+    o = rng.integers(-9, 10, (n, 3)).astype(np.float64)
+    d = np.zeros((n, 3)); d[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+    O_.append(o); D_.append(d)
+    # (5) towards the centroid of a random triangle, from far and from very near
+    a = rng.integers(0, T, n)
+    cen = v[a].mean(1)
+    src = np.where(rng.random((n, 1)) < 0.5, rng.uniform(-9, 9, (n, 3)), cen + rng.normal(size=(n, 3)) * 1e-3)
+    O_.append(src); D_.append(cen - src + 1e-12)
+    o = np.concatenate(O_).astype(np.float32)
+    d = _normalise(np.concatenate(D_).astype(np.float32))
+    ok = np.isfinite(d).all(1)
+    return o[ok], d[ok]
+
+
+def _check(g, o_scene, o, d, eps=1e-4):
+    gi, gt = g.trace_rays(o, d, eps)
+    ri, rt, nan_seen = o_scene.closest_hits(o, d, eps)
+    # Rays that lie EXACTLY in some triangle's stored plane (0/0 in PlaneIntersect) are outside the contract: the
+    # reference then accepts that triangle wherever it is, which no geometric cull can follow (deviations).
+    # They cannot come out of the integrator (no direction component is ever exactly zero there); only the lattice
+    # family below produces them.
+    assert nan_seen.mean() < 0.01
+    bad = np.flatnonzero(((gi != ri) | (gt.view(np.uint32) != rt.view(np.uint32))) & ~nan_seen)
+    assert bad.size == 0, (f"{bad.size} of {len(o)} rays differ; first: ray {bad[0]} o={o[bad[0]]} d={d[bad[0]]} "
+                           f"gpu=({gi[bad[0]]},{gt[bad[0]]}) oracle=({ri[bad[0]]},{rt[bad[0]]})")
+    return gi
+
+
+def test_tor_scene_rays(models_dir, oracle_scene):
+    g = pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+    tri, _ = oracle_scene.triangles()
+    o, d = _adversarial_rays(tri, np.random.default_rng(5), 120_000)
+    hits = _check(g, oracle_scene, o, d)
+    assert (hits >= 0).mean() > 0.5 and (hits < 0).sum() > 100      # both hits and misses are exercised
+    _check(g, oracle_scene, o[:50_000], d[:50_000], eps=1e-3)          # tables are rebuilt for another eps
+
+
+def test_empty_batch_and_device_rule(models_dir):
+    g = pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+    i, t = g.trace_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert len(i) == 0
+    h = pt.Scene.load_obj(models_dir, "Tor.obj", device=-1)
+    with pytest.raises(pt.PtError) as e:
+        h.trace_rays(np.zeros((1, 3), np.float32), np.array([[0, 0, 1]], np.float32))
+    assert e.value.status == 4
+
+
+def test_replicated_scene_rays(tmp_path):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_replicated_scene as M
+    d_ = str(tmp_path) + "/"
+    M.generate(os.path.join(root, "models"), d_, "x27.obj", 27)
+    g = pt.Scene.load_obj(d_, "x27.obj", device=0)
+    o_scene = O.Scene.load(d_, "x27.obj")
+    tri, _ = o_scene.triangles()
+    o, d = _adversarial_rays(tri, np.random.default_rng(6), 12_000)
+    _check(g, o_scene, o, d)
