@@ -9,7 +9,7 @@ One "step" = one complete frame: zero the accumulators, trace every sample of ev
 (all passes x segments x triangles in one kernel launch through the C ABI), and -- for N > 1 -- the single RCCL
 gather of the accumulator bands to rank 0.  At N = 1 the frame is BASELINE.json configs[1]: models/Tor.obj,
 1920x1080, 64 spp, -MRR 8, adaptive sampling off (-ERR -1, so all W*H*spp samples are traced).  For N > 1 the image
-grows with N (1920 x 1080*N... see frame_for()) so that every GPU keeps a 1080p-sized band: weak scaling.
+grows with N (path-tracing_amd/bands.py: frame_for) so that every GPU keeps a 1080p-sized band: weak scaling.
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   roofline      FP32 vector-ALU roofline of the integrator kernel (the path is neither HBM- nor
@@ -32,13 +32,6 @@ FLOP_PER_TEST = 31.5          # reference's own average over its
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 BASE_W, BASE_H, SPP, MRR = 1920, 1080, 64, 8
-
-
-def frame_for(n_gpus):
-    """Image whose row bands give every GPU 1920*1080 pixels (weak scaling).  N=4 is the 4K frame of configs[3]."""
-    if n_gpus % 4 == 0:
-        return BASE_W * 2, BASE_H * 2 * (n_gpus // 4)
-    return BASE_W, BASE_H * n_gpus
 
 
 def host_cores():
@@ -91,6 +84,7 @@ def main():
     import torch.distributed as dist
 
     pt = importlib.import_module("path-tracing_amd")
+    bands = importlib.import_module("path-tracing_amd.bands")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,17 +98,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    W, H = frame_for(world)
-    rows = H // world
-    r0, r1 = rank * rows, (rank + 1) * rows
+    W, H = bands.frame_for(world)
+    r0, r1 = bands.band_rows(H, world, rank)
+    rows = r1 - r0
     npx = rows * W
     models = os.path.join(ROOT, "models") + "/"
     scene = pt.Scene.load_obj(models, "Tor.obj", device=local)
     n_tri = scene.counts()[0]
 
     # one contiguous band buffer: sum[3n] | sum2[3n] | count[n] (int32 bits) -> a single gather moves everything
-    band = torch.zeros(7 * npx, dtype=torch.float32, device=dev)
-    full = [torch.empty_like(band) for _ in range(world)] if (world > 1 and rank == 0) else None
+    band = torch.zeros(bands.band_floats(W, rows), dtype=torch.float32, device=dev)
+    gathered = [None]
     p_sum, p_sum2, p_cnt = band.data_ptr(), band.data_ptr() + 12 * npx, band.data_ptr() + 24 * npx
     params = pt.RenderParams(W, H, r0, r1, 0, args.spp, MRR, 1e-4, -1.0, 42)
     stream = torch.cuda.current_stream(dev)
@@ -123,7 +117,7 @@ def main():
         band.zero_()
         st = scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=True)
         if world > 1:
-            dist.gather(band, full, dst=0)
+            gathered[0] = bands.gather_bands(band, W, H, dist, rank, world)   # the frame's one collective (RCCL)
         return st
 
     def fence():
@@ -188,13 +182,8 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(models, args.cpu_seconds)
         if args.write_bmp:
-            if world > 1:
-                parts = [t.cpu().numpy() for t in full]
-            else:
-                parts = [band.cpu().numpy()]
-            s = np.concatenate([p[:3 * npx] for p in parts]).reshape(-1, 3)
-            s2 = np.concatenate([p[3 * npx:6 * npx] for p in parts]).reshape(-1, 3)
-            c = np.concatenate([p[6 * npx:].view(np.int32) for p in parts])
+            parts = [t.cpu().numpy() for t in gathered[0]] if world > 1 else [band.cpu().numpy()]
+            s, s2, c = bands.assemble(parts, W, H, world)
             bgr, disp = pt.resolve(W, H, s, s2, c)
             pt.write_bmp(args.write_bmp, bgr)
             out["config"]["dispersion_max_min_avg"] = [float(d) for d in disp]

@@ -124,6 +124,15 @@ int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum
 /* bitmap_image::save_image (bitmap_image.hpp:431-478): 54-byte header, bottom-up rows padded to 4 bytes. */
 int pt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t *bgr);
 
+/* ---- diagnostics ---------------------------------------------------------------------------------- */
+
+/* The culling hierarchy built for `eps` (host side; works on device < 0 scenes).  counts[4] = clusters, sphere
+ * records, barycentric records, triangles handled by the barycentric class.  Pass NULL tables to query counts only.
+ * clusters: 8 words each (centre[3], r2, first_tri, n_tri, kind, data_off -- the last four as uint32 bit patterns);
+ * spheres: 4 floats each (centre[3], r2); bary: 12 floats each; constants: k1, k2, a_max, m0, t_guard. */
+int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary,
+                         float *constants);
+
 /* ---- misc ------------------------------------------------------------------------------------------- */
 int pt_abi_version(void);
 int pt_device_count(void);

@@ -24,7 +24,7 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT
 # every symbol include/pt_hip.h declares
 ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
                "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_trace_rays_host",
-               "pt_resolve",
+               "pt_scene_cull_tables", "pt_resolve",
                "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
 
 
@@ -78,6 +78,7 @@ def lib():
         L.pt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, C.POINTER(RenderStats)]
         L.pt_render_host.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.POINTER(RenderStats)]
         L.pt_trace_rays_host.argtypes = [vp, C.c_int32, fp, fp, C.c_float, ip, fp]
+        L.pt_scene_cull_tables.argtypes = [vp, C.c_float, ip, fp, fp, fp, fp]
         L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
         L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.pt_last_error.restype = C.c_char_p
@@ -153,6 +154,20 @@ class Scene:
         st = RenderStats()
         _check(lib().pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None))
         return s, s2, c, st.as_dict()
+
+    def cull_tables(self, eps=1e-4):
+        """The culling hierarchy for `eps` (diagnostics): dict of clusters, spheres, bary records, constants."""
+        counts = np.zeros(4, np.int32)
+        _check(lib().pt_scene_cull_tables(self._h, eps, _ip(counts), None, None, None, None))
+        cl = np.zeros((counts[0], 8), np.float32)
+        sp = np.zeros((counts[1], 4), np.float32)
+        ba = np.zeros((counts[2], 12), np.float32)
+        k = np.zeros(5, np.float32)
+        _check(lib().pt_scene_cull_tables(self._h, eps, _ip(counts), _fp(cl), _fp(sp), _fp(ba), _fp(k)))
+        meta = cl[:, 4:8].view(np.uint32)
+        return {"cluster_sphere": cl[:, :4], "first_tri": meta[:, 0].astype(int), "n_tri": meta[:, 1].astype(int),
+                "kind": meta[:, 2].astype(int), "data_off": meta[:, 3].astype(int), "spheres": sp, "bary": ba,
+                "constants": dict(zip(["k1", "k2", "a_max", "m0", "t_guard"], k.tolist())), "n_large": int(counts[3])}
 
     def trace_rays(self, origins, directions, eps=1e-4):
         """Closest hit per ray (scene.cpp:114-120).  directions must be unit length (normalised as ray.h:23 does)."""

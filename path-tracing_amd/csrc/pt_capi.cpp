@@ -341,6 +341,28 @@ int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float
     return result;
 }
 
+int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary,
+                         float *constants) {
+    if (!scene || !counts) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    pt::CullTables t;
+    pt::build_cull_tables(scene->host, eps, t);
+    counts[0] = static_cast<int32_t>(t.clusters.size());
+    counts[1] = static_cast<int32_t>(t.spheres.size());
+    counts[2] = static_cast<int32_t>(t.bary.size());
+    int32_t large = 0;
+    for (const auto &c : t.clusters)
+        if (c.kind == 1) large += static_cast<int32_t>(c.n_tri);
+    counts[3] = large;
+    if (clusters) std::memcpy(clusters, t.clusters.data(), t.clusters.size() * sizeof(pt::ClusterDesc));
+    if (spheres) std::memcpy(spheres, t.spheres.data(), t.spheres.size() * sizeof(pt::SphereRec));
+    if (bary) std::memcpy(bary, t.bary.data(), t.bary.size() * sizeof(pt::CullRec));
+    if (constants) {
+        constants[0] = t.cc.k1; constants[1] = t.cc.k2; constants[2] = t.cc.a_max; constants[3] = t.cc.m0;
+        constants[4] = t.cc.t_guard;
+    }
+    return PT_OK;
+}
+
 int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
                uint8_t *bgr, float *dispersion) {
     if (width <= 0 || height <= 0 || !sum || !sum2 || !count || !bgr)

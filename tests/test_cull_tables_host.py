@@ -1,0 +1,111 @@
+"""CPU checks of the culling hierarchy the host builds (pt_scene.cpp: build_cull_tables): structure, containment, and
+the property everything rests on -- a triangle the reference ACCEPTS for a ray is never culled for that ray."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pt = importlib.import_module("path-tracing_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ray_sphere_keep(c, r2, o, d):
+    """float64 model of sphere_keep() in pt_kernels.hip (the float32 rounding slack is part of r2)."""
+    m = c - o
+    b = np.maximum((m * d).sum(-1), 0.0)
+    return ~((m * m).sum(-1) - b * b > r2)
+
+
+def _layout(t):
+    """triangle index -> (cluster, word, octet sphere index, triangle sphere index) for the small class."""
+    out = {}
+    for ci in range(len(t["kind"])):
+        if t["kind"][ci] != 0:
+            continue
+        for k in range(t["n_tri"][ci]):
+            w, j = divmod(k, 32)
+            base = t["data_off"][ci] + 36 * w
+            out[t["first_tri"][ci] + k] = (ci, base + j // 8, base + 4 + j)
+    return out
+
+
+@pytest.fixture(scope="module")
+def tor(models_dir):
+    return pt.Scene.load_obj(models_dir, "Tor.obj", device=-1)
+
+
+def test_structure_tor(tor):
+    t = tor.cull_tables()
+    assert list(t["first_tri"]) == [0, 256, 258, 260] and list(t["n_tri"]) == [256, 2, 2, 10]
+    assert list(t["kind"]) == [0, 1, 0, 1]          # torus + light: spheres; walls: barycentric
+    assert t["n_large"] == 12
+    tri, _ = tor.triangles()
+    v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
+    lay = _layout(t)
+    assert sorted(lay) == list(range(256)) + [258, 259]
+    for i, (ci, so, st) in lay.items():
+        for sph in (t["cluster_sphere"][ci], t["spheres"][so], t["spheres"][st]):
+            assert (((v[i] - sph[:3]) ** 2).sum(1) <= sph[3]).all()      # vertices inside every enclosing sphere
+    # padding records can never keep a finite ray
+    pads = t["spheres"][t["spheres"][:, 3] < 0]
+    assert len(pads) > 0 and (pads[:, 3] <= -1e29).all()
+    # the triangle spheres really are small compared with the octet and cluster spheres
+    r_tri = np.sqrt([t["spheres"][st][3] for _, _, st in lay.values()])
+    assert np.median(r_tri) < 1.0 and np.sqrt(t["cluster_sphere"][0][3]) < 4.5
+
+
+def test_accepted_triangles_are_never_culled(tor, oracle_scene):
+    """Every (ray, triangle) pair the reference's Triangle::Intersect accepts passes all three sphere levels."""
+    import ctypes as C
+    t = tor.cull_tables()
+    lay = _layout(t)
+    tri, _ = tor.triangles()
+    rng = np.random.default_rng(17)
+    v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
+    # rays aimed at random points of small triangles (inside, on edges, just outside), from random origins
+    small = np.array(sorted(lay))
+    n = 40000
+    a = small[rng.integers(0, len(small), n)]
+    w = rng.dirichlet([0.6, 0.6, 0.6], n) * rng.choice([1.0, 1.0, 1.001, 1.01], n)[:, None]
+    target = (v[a] * w[:, :, None]).sum(1)
+    org = rng.uniform([-9.5, -9.5, -20.5], [9.5, 9.5, 9.5], (n, 3))
+    d = (target - org).astype(np.float32)
+    inv = np.float32(1) / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
+    d = d * inv[:, None]
+    o32 = org.astype(np.float32)
+    accepted = 0
+    best = C.c_float()
+    L = O.lib()
+    for i in range(n):
+        stage = L.orc_probe_intersect(oracle_scene.h, int(a[i]), o32[i].ctypes.data_as(C.POINTER(C.c_float)),
+                                      d[i].ctypes.data_as(C.POINTER(C.c_float)), 1e-4, np.float32(np.inf), C.byref(best))
+        if stage != 4:
+            continue
+        accepted += 1
+        ci, so, st = lay[int(a[i])]
+        o64, d64 = o32[i].astype(np.float64), d[i].astype(np.float64)
+        for sph in (t["cluster_sphere"][ci], t["spheres"][so], t["spheres"][st]):
+            assert _ray_sphere_keep(sph[:3].astype(np.float64), float(sph[3]), o64, d64)
+    assert accepted > 0.5 * n
+
+
+def test_degenerate_and_tiny_triangles_are_always_kept(tmp_path):
+    (tmp_path / "d.mtl").write_text("newmtl 0\nKd 1 1 1\n")
+    (tmp_path / "d.obj").write_text("mtllib d.mtl\nv 0 0 0\nv 1 0 0\nv 2 0 0\nv 0 0.001 0\nv 0.001 0 0\nv 5 5 5\nv 6 5 5\nv 5 6 5\n"
+                                    "usemtl 0\nf 1 2 3\nf 1 4 5\nf 6 7 8\n")
+    s = pt.Scene.load_obj(str(tmp_path) + "/", "d.obj", device=-1)
+    t = s.cull_tables()
+    lay = _layout(t)
+    # collinear triangle 0 and the 1e-6-area triangle 1 (area below a few eps) get infinite spheres
+    assert np.isinf(t["spheres"][lay[0][2]][3]) and np.isinf(t["spheres"][lay[1][2]][3])
+    assert np.isfinite(t["spheres"][lay[2][2]][3])
+
+
+def test_tables_depend_on_eps(tor):
+    a, b = tor.cull_tables(1e-4), tor.cull_tables(1e-2)
+    assert (b["spheres"][:, 3] >= a["spheres"][:, 3]).all()
+    assert b["constants"]["m0"] > a["constants"]["m0"]
