@@ -68,7 +68,7 @@ int upload(pt_scene *s, int device) {
     const auto &t = s->tables;
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_exact), t.exact.size() * sizeof(pt::ExactRec) + 64));
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_mats), t.mats.size() * sizeof(pt::MatRec) + 64));
-    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 8 * sizeof(unsigned long long)));
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 16 * sizeof(unsigned long long)));
     if (!t.exact.empty()) PT_HIP_TRY(hipMemcpy(s->d_exact, t.exact.data(), t.exact.size() * sizeof(pt::ExactRec), hipMemcpyHostToDevice));
     if (!t.mats.empty()) PT_HIP_TRY(hipMemcpy(s->d_mats, t.mats.data(), t.mats.size() * sizeof(pt::MatRec), hipMemcpyHostToDevice));
     PT_HIP_TRY(hipEventCreate(&s->ev0));
@@ -240,13 +240,13 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
     a.blocks_x = (p->width + 7) / 8;
     if (stats) {
-        PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 8 * sizeof(unsigned long long), stream));
+        PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
         PT_HIP_TRY(hipEventRecord(scene->ev0, stream));
     }
     PT_HIP_TRY(pt::launch_integrator(a, stream));
     if (stats) {
         PT_HIP_TRY(hipEventRecord(scene->ev1, stream));
-        unsigned long long h[8];
+        unsigned long long h[16];
         PT_HIP_TRY(hipMemcpyAsync(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
         PT_HIP_TRY(hipStreamSynchronize(stream));
         float ms = -1.0f;
@@ -261,6 +261,11 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
         stats->wave_exact_iterations = h[7];
         stats->kernel_ms = ms;
         stats->n_triangles = scene->host.n_tri();
+#ifdef PT_PHASE_TIMERS
+        std::fprintf(stderr, "PT_PHASE_TIMERS cycles:");
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[8 + k]);
+        std::fprintf(stderr, "\n");
+#endif
     }
     return PT_OK;
 }

@@ -30,8 +30,8 @@ namespace {
 #define PT_WAVES_PER_SIMD 6
 #endif
 constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per workgroup (all LDS below is wave-private)
-constexpr int kSlots = 12;                // candidate-mask words (32 triangles each) parked per lane between cull and exact
-constexpr int kQueue = 128;               // work items per batch of the two lane-balanced queues
+constexpr int kOctetQueue = 192;          // (lane, octet) work items the wave can park (drained in rounds of 64)
+constexpr int kPairQueue = 256;           // (lane, triangle) work items the wave can park
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -210,82 +210,90 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // flow: all 64 lanes must call it together; lanes with valid == false take part in the shared work only.
 // ---------------------------------------------------------------------------------------------------------------
 struct WaveLds {
-    uint32_t cand[kSlots][64];   // per lane: candidate bits of one 32-triangle word
-    uint32_t first[kSlots];      // index of the word's first triangle
-    uint32_t live[kSlots];       // bits of the word that are real triangles
-    float ray[6][64];            // this segment's rays, readable by every lane
-    uint32_t queue[kQueue];      // work items: (octet | lane << 8) or (triangle | lane << 24)
-    float res[kQueue];           // per (ray, triangle) item: t if inside, -inf otherwise
+    unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
+    float ray[6][64];              // this segment's rays, readable by every lane
+    uint32_t octets[kOctetQueue];  // work items: octet number inside the cluster | lane << 8
+    uint32_t pairs[kPairQueue];    // work items: triangle index | lane << 24
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_octets = 0, w_exact_iters = 0;   // wave-uniform, live in SGPRs
+#ifdef PT_PHASE_TIMERS
+    // diagnostic build only: shader-clock cycles per phase (never compiled into the shipped library)
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last = 0;
+#endif
 };
+#ifdef PT_PHASE_TIMERS
+#define PT_STAMP(st, idx)                                              \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        (st).phase[idx] += now_ - (st).last;                           \
+        (st).last = now_;                                              \
+    } while (0)
+#else
+#define PT_STAMP(st, idx) do { } while (0)
+#endif
+
+// float -> uint32 whose unsigned order is the float order (for ds_min_u64 keys)
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t b) {
+    return __uint_as_float(b ^ ((b >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
 
 __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, const Ray &q, bool valid, int lane,
                                             float eps, float &best, int &hit, WaveStats &st) {
     ++st.w_segments;
-    best = __builtin_inff();
-    hit = -1;
-    int n_slots = 0;   // wave-uniform
-
-    // every lane's ray, for the lane-balanced phases
+    PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
+    lds.best[lane] = ~0ull;
     lds.ray[0][lane] = q.ox; lds.ray[1][lane] = q.oy; lds.ray[2][lane] = q.oz;
     lds.ray[3][lane] = q.dx; lds.ray[4][lane] = q.dy; lds.ray[5][lane] = q.dz;
+    uint32_t n_pairs = 0;   // wave-uniform fill level of lds.pairs
+    wave_sync();
 
-    // ---- 2. exact.  The candidates parked in lds.cand are spread evenly over the lanes (a lane works on other
-    // lanes' rays), each (ray, triangle) pair yields t and the outcome of stages B-D of Triangle::Intersect,
-    // and every lane then replays its own pairs in triangle order with the reference's running `distance`
-    // (stage A, triangles.h:51), so the closest-hit choice is the reference's, ties and NaNs included.
-    auto flush = [&]() {
-        uint32_t mine = 0;
-        for (int sl = 0; sl < n_slots; ++sl) {
-            const uint32_t m = lds.cand[sl][lane] & lds.live[sl];
-            lds.cand[sl][lane] = m;
-            mine += __builtin_popcount(m);
-        }
-        const uint32_t incl = wave_inclusive_scan(mine, lane);
-        const uint32_t start = incl - mine;
-        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        int c = -1;            // cursor over this lane's candidates
-        uint32_t m = 0, k = 0;
-        for (uint32_t base = 0; base < total; base += kQueue) {
-            const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
-            // (a) publish this lane's pairs that fall into the batch, in triangle order
-            const uint32_t k_first = k;
-            while (k < mine && start + k < base + kQueue) {
-                while (m == 0) { ++c; m = lds.cand[c][lane]; }
-                const uint32_t j = __builtin_ctz(m);
-                m &= m - 1;
-                lds.queue[start + k - base] = (lds.first[c] + j) | (static_cast<uint32_t>(lane) << 24);
-                ++k;
-            }
-            wave_sync();
-            // (b) balanced: lane l takes pairs l, l+64, ...
-            for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
-                ++st.w_exact_iters;
-                const uint32_t i = i0 + lane;
-                if (i < n_in) {
-                    const uint32_t e = lds.queue[i];
-                    const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
-                    Ray r;
-                    r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
-                    r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
-                    lds.res[i] = exact_inside(a.exact + tri, r, eps);
-                }
-            }
-            st.n_exact += n_in;
-            wave_sync();
-            // (c) replay in triangle order (scene.cpp:116-120 with the stage-A test of triangles.h:51)
-            for (uint32_t kk = k_first; kk < k; ++kk) {
-                const float nd = lds.res[start + kk - base];
-                if (!(nd >= best || nd < eps)) {
-                    best = nd;
-                    hit = static_cast<int>(lds.queue[start + kk - base] & 0xFFFFFFu);
-                }
+    // ---- 2. exact.  (ray, triangle) pairs are spread evenly over the lanes (a lane works on other lanes' rays).
+    // The reference keeps, in triangle order, every accepted triangle with new_distance < distance
+    // (scene.cpp:116-120, triangles.h:51), i.e. the lexicographic minimum of (new_distance, index) over the triangles
+    // that pass Triangle::Intersect with eps <= new_distance < inf: that minimum is taken with one LDS atomic per pair.
+    auto drain_pairs = [&](uint32_t keep_below) {
+        while (n_pairs > keep_below) {
+            const uint32_t cnt = min(64u, n_pairs);
+            n_pairs -= cnt;
+            ++st.w_exact_iters;
+            st.n_exact += cnt;
+            if (static_cast<uint32_t>(lane) < cnt) {
+                const uint32_t e = lds.pairs[n_pairs + lane];
+                const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
+                Ray r;
+                r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                const float nd = exact_inside(a.exact + tri, r, eps);   // -inf unless stages B-D pass
+                if (nd >= eps && nd < __builtin_inff())
+                    atomicMin(&lds.best[src], (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | tri);
             }
             wave_sync();
         }
-        n_slots = 0;
+    };
+    // Append one pair per set bit of `bits` (bit j = triangle tri0 + j of ray `src`), compacting over the wave.
+    auto push_pairs = [&](uint32_t bits, uint32_t tri0, uint32_t src) {
+        while (__any(bits != 0)) {
+            const bool has = bits != 0;
+            const unsigned long long ball = __ballot(has);
+            if (has) {
+                const uint32_t j = __builtin_ctz(bits);
+                bits &= bits - 1;
+                lds.pairs[n_pairs + lanes_below(ball)] = (tri0 + j) | (src << 24);
+            }
+            n_pairs += __builtin_popcountll(ball);
+            wave_sync();
+            if (n_pairs > kPairQueue - 64) drain_pairs(63);   // keeps whole rounds only
+        }
     };
 
     // ---- 1. cull
@@ -298,7 +306,6 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
         if (!__any(pc)) continue;
         const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
         const int n_words = static_cast<int>((n_tri + kChunk - 1) / kChunk);
-        if (n_slots + n_words > kSlots) flush();
         if (kind == 0) {
             // (a) every lane against the cluster's octet spheres (wave-uniform, records in SGPRs)
             uint32_t omask = 0;
@@ -311,52 +318,51 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
                 }
             }
             omask = pc ? omask : 0u;
-            if (!__any(omask != 0)) continue;
-            for (int w = 0; w < n_words; ++w) {
-                lds.cand[n_slots + w][lane] = 0;
-                if (lane == 0) {
-                    const uint32_t left = n_tri - kChunk * w;
-                    lds.first[n_slots + w] = first_tri + kChunk * w;
-                    lds.live[n_slots + w] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
-                }
-            }
-            // (b) the (lane, octet) pairs that survived, spread evenly over the lanes: 8 triangle spheres each
-            const uint32_t mine = __builtin_popcount(omask);
-            const uint32_t incl = wave_inclusive_scan(mine, lane);
-            const uint32_t start = incl - mine;
-            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-            uint32_t om = omask, k = 0;
-            for (uint32_t base = 0; base < total; base += kQueue) {
-                const uint32_t n_in = min(static_cast<uint32_t>(kQueue), total - base);
-                while (k < mine && start + k < base + kQueue) {
-                    const uint32_t b = __builtin_ctz(om);
-                    om &= om - 1;
-                    lds.queue[start + k - base] = b | (static_cast<uint32_t>(lane) << 8);
-                    ++k;
-                }
-                wave_sync();
-                for (uint32_t i0 = 0; i0 < n_in; i0 += 64) {
+            PT_STAMP(st, 1);   // cluster + octet sphere tests
+            // (b) the surviving (lane, octet) items, spread evenly over the lanes: 8 triangle spheres each
+            uint32_t n_items = 0;
+            auto drain_octets = [&]() {
+                for (uint32_t i0 = 0; i0 < n_items; i0 += 64) {
                     ++st.w_octets;
                     const uint32_t i = i0 + lane;
-                    if (i < n_in) {
-                        const uint32_t e = lds.queue[i];
-                        const uint32_t src = e >> 8, b = e & 31u;
+                    uint32_t m8 = 0, src = 0, tri0 = 0;
+                    if (i < n_items) {
+                        const uint32_t e = lds.octets[i];
+                        src = e >> 8;
+                        const uint32_t b = e & 31u;
                         Ray r;
                         r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                         r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
                         const float4 *tp = reinterpret_cast<const float4 *>(a.spheres) + off + 36u * (b >> 2) + 4u + 8u * (b & 3u);
-                        uint32_t m8 = 0;
 #pragma unroll
                         for (int t8 = 0; t8 < kOctet; ++t8) {
                             const float4 sp = tp[t8];
                             m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << t8) : 0u;
                         }
-                        if (m8) atomicOr(&lds.cand[n_slots + (b >> 2)][src], m8 << (8u * (b & 3u)));
+                        const uint32_t local = 8u * b;   // first triangle of the octet, relative to the cluster
+                        const uint32_t left = n_tri > local ? n_tri - local : 0u;
+                        m8 &= left >= 8u ? 0xFFu : ((1u << left) - 1u);   // padding spheres are never candidates
+                        tri0 = first_tri + local;
                     }
+                    push_pairs(m8, tri0, src);
                 }
+                n_items = 0;
+            };
+            uint32_t om = omask;
+            while (__any(om != 0)) {
+                const bool has = om != 0;
+                const unsigned long long ball = __ballot(has);
+                if (has) {
+                    const uint32_t b = __builtin_ctz(om);
+                    om &= om - 1;
+                    lds.octets[n_items + lanes_below(ball)] = b | (static_cast<uint32_t>(lane) << 8);
+                }
+                n_items += __builtin_popcountll(ball);
                 wave_sync();
+                if (n_items > kOctetQueue - 64) drain_octets();
             }
-            n_slots += n_words;
+            drain_octets();
+            PT_STAMP(st, 2);   // balanced octet expansion
         } else {
             // large triangles: barycentric cull, wave-uniform over the triangles.
             // The margins go to VGPRs here: a VALU instruction can name only one SGPR, so an SGPR-resident
@@ -367,27 +373,28 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
                 const uint32_t left = n_tri - kChunk * w;
                 const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
                 uint32_t m = 0;
-                for (uint32_t k0 = 0; k0 < min(left, 32u); k0 += 4) {   // records are padded to whole words
+                for (uint32_t k0 = 0; k0 < min(left, 32u); k0 += 2) {   // records are padded to whole words
 #pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) {
+                    for (uint32_t j = 0; j < 2; ++j) {
                         const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
                         m |= rej ? 0u : (1u << (k0 + j));
                     }
                 }
                 m = pc ? m : 0u;
-                if (__any(m != 0)) {
-                    lds.cand[n_slots][lane] = m;
-                    if (lane == 0) {
-                        lds.first[n_slots] = first_tri + kChunk * w;
-                        lds.live[n_slots] = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
-                    }
-                    ++n_slots;
-                }
+                m &= left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                PT_STAMP(st, 3);   // barycentric cull of the large triangles
+                push_pairs(m, first_tri + kChunk * w, static_cast<uint32_t>(lane));
+                PT_STAMP(st, 4);   // pair publication
             }
         }
-        wave_sync();
     }
-    if (n_slots > 0) flush();
+    PT_STAMP(st, 1);
+    drain_pairs(0);
+    PT_STAMP(st, 5);   // exact rounds
+    const unsigned long long key = lds.best[lane];
+    hit = (key == ~0ull) ? -1 : static_cast<int>(key & 0xFFFFFFFFu);
+    best = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
+    wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -411,6 +418,9 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
     // statistics are wave-level (uniform) counts: they live in SGPRs
     uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_miss = 0;
     WaveStats wst;
+#ifdef PT_PHASE_TIMERS
+    wst.last = __builtin_amdgcn_s_memtime();
+#endif
 
     const int mrr = a.mrr;
     const float eps = a.eps;
@@ -525,6 +535,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
                 }
             }
             n_contrib += __builtin_popcountll(__ballot(contributed));
+            PT_STAMP(wst, 7);   // shading
         }
     }
 
@@ -537,6 +548,9 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
         atomicAdd(&a.stats[5], static_cast<unsigned long long>(wst.w_segments));
         atomicAdd(&a.stats[6], static_cast<unsigned long long>(wst.w_octets));
         atomicAdd(&a.stats[7], static_cast<unsigned long long>(wst.w_exact_iters));
+#ifdef PT_PHASE_TIMERS
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[8 + k], wst.phase[k]);
+#endif
     }
 }
 
