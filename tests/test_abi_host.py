@@ -120,3 +120,17 @@ def test_reference_frame_through_product_resolve(tmp_path, oracle_scene):
     pt.write_bmp(path, bgr)
     assert hashlib.md5(open(path, "rb").read()).hexdigest() == "994782793a83d584cb8f0815a5a65b90"
     assert "%f" % disp[2] == "0.986328"
+
+
+def test_cli_fails_loudly_without_gpu(models_dir, tmp_path):
+    import subprocess
+    exe = os.path.join(ROOT, "path-tracing_amd", "bin", "pt_render")
+    if not os.path.exists(exe):
+        pt.build()
+    if pt.device_count() > 0:
+        pytest.skip("a GPU is present; the GPU suite covers the CLI")
+    r = subprocess.run([exe, "--W", "8", "--H", "8", "-RPP", "1", "-MODEL_PATH", models_dir], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    r = subprocess.run([exe, "-GAUSS", "2"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 2

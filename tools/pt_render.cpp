@@ -1,0 +1,148 @@
+// pt_render -- command-line front end with the reference's flag set (config.h:35-99) on top of libpt_hip.so.
+//
+// It plays the part of the reference's main() (main.cpp:87-215): parse flags, load the model, run the passes, write
+// previews every `-UPDATE` passes, stop at the `-TL` time limit, print the per-pass progress lines, then resolve,
+// and write "<date>  <ms>   <n> of <rpp>  max_disp .. min_disp .. aver_disp ...bmp" plus "../result.bmp".
+// The passes themselves run on the GPU through the C ABI; nothing here computes radiance.
+//
+// Extra flags (not in the reference): -OUT <file> writes only that file instead of the two reference outputs,
+// -DEVICE <n> selects the HIP device, -QUIET 1 drops the per-pass lines.
+// Not available in this build (SURVEY.md 8(f) "next" rows): -GAUSS, -MEDIAN, -SKYBOX with a non-default value.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "pt_hip.h"
+
+namespace {
+
+struct Options {   // defaults: config.h:16-29
+    int height = 512, width = 512, rays_per_pixel = 20, max_ray_reflections = 8, median = 0, gauss = 0;
+    float eps = 1e-4f, error = 0.001f;
+    int update = 32;
+    float gamma_correction = 1 / 2.2f;
+    std::string model_path = "../models/", model_name = "Tor.obj", skybox;
+    int seed = 42, time_limit = 0;
+    std::string out;
+    int device = 0, quiet = 0;
+};
+
+long long now_ms() {
+    using namespace std::chrono;
+    return duration_cast<milliseconds>(system_clock::now().time_since_epoch()).count();
+}
+
+void parse(int argc, char **argv, Options &o) {   // pairs `flag value` from argv[1] on, unknown flags ignored
+    for (int i = 1; i < argc - 1; i += 2) {
+        const std::string f = argv[i];
+        const char *v = argv[i + 1];
+        if (f == "--H") o.height = std::atoi(v);
+        if (f == "--W") o.width = std::atoi(v);
+        if (f == "-RPP") o.rays_per_pixel = std::atoi(v);
+        if (f == "-MRR") o.max_ray_reflections = std::atoi(v);
+        if (f == "-EPS") o.eps = static_cast<float>(std::atof(v));
+        if (f == "-ERR") o.error = static_cast<float>(std::atof(v));
+        if (f == "-MEDIAN") { o.median = std::atoi(v); o.gauss = 0; }
+        if (f == "-UPDATE") o.update = std::atoi(v);
+        if (f == "-MODEL_PATH") o.model_path = v;
+        if (f == "-MODEL_NAME") o.model_name = v;
+        if (f == "-GAUSS") { o.gauss = std::atoi(v); o.median = 0; }
+        if (f == "-GAMMA") o.gamma_correction = static_cast<float>(std::atof(v));
+        if (f == "-SKYBOX") o.skybox = v;
+        if (f == "-SEED") o.seed = std::atoi(v);
+        if (f == "-TL") o.time_limit = std::atoi(v);
+        if (f == "-OUT") o.out = v;
+        if (f == "-DEVICE") o.device = std::atoi(v);
+        if (f == "-QUIET") o.quiet = std::atoi(v);
+    }
+}
+
+int die(const char *what) {
+    std::cerr << what << ": " << pt_last_error() << std::endl;
+    return 1;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const long long start_time = now_ms();
+    Options o;
+    parse(argc, argv, o);
+    if (o.gauss || o.median || !o.skybox.empty()) {
+        std::cerr << "pt_render: -GAUSS / -MEDIAN / -SKYBOX are not part of this build (post filters and the skybox "
+                     "miss shader are the next rows of the hot-path plan)" << std::endl;
+        return 2;
+    }
+    if (o.width <= 0 || o.height <= 0) {
+        std::cerr << "pt_render: --W and --H must be positive" << std::endl;
+        return 2;
+    }
+    const unsigned seed = o.seed < 0 ? static_cast<unsigned>(std::time(nullptr)) : static_cast<unsigned>(o.seed);   // config.h:101-104
+
+    pt_scene *scene = nullptr;
+    if (pt_scene_load_obj(o.model_path.c_str(), o.model_name.c_str(), o.device, &scene) != PT_OK) return die("pt_render");
+
+    const size_t px = static_cast<size_t>(o.width) * o.height;
+    std::vector<float> sum(3 * px, 0.0f), sum2(3 * px, 0.0f);
+    std::vector<int32_t> count(px, 0);
+    std::vector<uint8_t> bgr(3 * px);
+    float disp[3] = {0, INFINITY, 0};
+
+    pt_render_params rp;
+    std::memset(&rp, 0, sizeof rp);
+    rp.width = o.width; rp.height = o.height; rp.row_begin = 0; rp.row_end = o.height;
+    rp.max_ray_reflections = o.max_ray_reflections;
+    rp.eps = o.eps; rp.error = o.error; rp.seed = seed;
+
+    // Pass slices end exactly where the reference writes a preview (after every pass p with p % update == 0,
+    // main.cpp:144-158) so that previews and the -TL check (main.cpp:111-114) happen between GPU calls.
+    int rays_count = 0;
+    while (rays_count < o.rays_per_pixel) {
+        if (o.time_limit != 0 && now_ms() - start_time >= 1000LL * o.time_limit) break;
+        int slice_end = o.rays_per_pixel;
+        if (o.update != 0) {
+            const int next_preview = (rays_count % o.update == 0) ? rays_count : (rays_count / o.update + 1) * o.update;
+            slice_end = std::min(o.rays_per_pixel, next_preview + 1);
+        }
+        rp.pass_begin = rays_count;
+        rp.pass_count = slice_end - rays_count;
+        if (pt_render_host(scene, &rp, sum.data(), sum2.data(), count.data(), nullptr) != PT_OK) return die("pt_render");
+        for (int p = rays_count; p < slice_end; ++p) {
+            if (o.update != 0 && p % o.update == 0) {
+                pt_resolve(o.width, o.height, sum.data(), sum2.data(), count.data(), o.gamma_correction, bgr.data(), nullptr);
+                if (o.out.empty() && pt_write_bmp("../result.bmp", o.width, o.height, bgr.data()) != PT_OK)
+                    std::cerr << pt_last_error() << std::endl;   // the reference's save_image only prints, too
+                std::cerr << "Image update" << std::endl;
+            }
+            if (!o.quiet) std::cerr << p + 1 << " rays per pixel were sent" << std::endl;
+        }
+        rays_count = slice_end;
+    }
+
+    pt_resolve(o.width, o.height, sum.data(), sum2.data(), count.data(), o.gamma_correction, bgr.data(), disp);
+    const long long end_time = now_ms();
+    const std::time_t t = std::time(nullptr);
+    const std::tm *now = std::localtime(&t);
+    const std::string name =   // main.cpp:206-213
+        std::to_string(now->tm_year + 1900) + '-' + std::to_string(now->tm_mon + 1) + '-' + std::to_string(now->tm_mday) + '-' +
+        std::to_string(now->tm_hour) + '-' + std::to_string(now->tm_min) + '-' + std::to_string(now->tm_sec) + "  " +
+        std::to_string(end_time - start_time) + "   " + std::to_string(rays_count) + " of " + std::to_string(o.rays_per_pixel) +
+        "  max_disp " + std::to_string(disp[0]) + "  min_disp " + std::to_string(disp[1]) + "  aver_disp " + std::to_string(disp[2]);
+    int rc = 0;
+    if (!o.out.empty()) {
+        if (pt_write_bmp(o.out.c_str(), o.width, o.height, bgr.data()) != PT_OK) rc = die("pt_render");
+    } else {
+        if (pt_write_bmp((name + ".bmp").c_str(), o.width, o.height, bgr.data()) != PT_OK) rc = die("pt_render");
+        if (pt_write_bmp("../result.bmp", o.width, o.height, bgr.data()) != PT_OK) rc = die("pt_render");
+    }
+    std::cout << name << std::endl;
+    pt_scene_destroy(scene);
+    return rc;
+}
