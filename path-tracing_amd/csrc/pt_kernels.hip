@@ -27,7 +27,7 @@ namespace pt {
 namespace {
 
 #ifndef PT_WAVES_PER_SIMD
-#define PT_WAVES_PER_SIMD 6
+#define PT_WAVES_PER_SIMD 7
 #endif
 constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per workgroup (all LDS below is wave-private)
 constexpr int kOctetQueue = 192;          // (lane, octet) work items the wave can park (drained in rounds of 64)
@@ -40,8 +40,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const unsigned long long p0 = static_cast<unsigned long long>(c0) * 0xD2511F53u;   // one v_mad_u64_u32 each
+        const unsigned long long p1 = static_cast<unsigned long long>(c2) * 0xCD9E8D57u;
+        const uint32_t h0 = static_cast<uint32_t>(p0 >> 32), l0 = static_cast<uint32_t>(p0);
+        const uint32_t h1 = static_cast<uint32_t>(p1 >> 32), l1 = static_cast<uint32_t>(p1);
         c0 = h1 ^ c1 ^ k0;
         c1 = l1;
         c2 = h0 ^ c3 ^ k1;
