@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 output directories into the small summaries committed under profiles/.
+
+    python tools/summarize_pmc.py --tag r01 --kernel-trace gpurun_out/prof_kt --pmc gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq ...
+
+Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3's --stats table) and profiles/<tag>_pmc_hbm.json with the
+counters of pt::integrate_kernel per launch.  HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE are in
+KiB, collected in separate passes, and FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B).
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--kernel-trace", default="")
+    ap.add_argument("--pmc", nargs="*", default=[])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--launches-per-pass", type=int, default=1)
+    a = ap.parse_args()
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    if a.kernel_trace:
+        f = glob.glob(os.path.join(a.kernel_trace, "*", "*_kernel_stats.csv"))[0]
+        shutil.copy(f, os.path.join(out_dir, f"{a.tag}_kernel_stats.csv"))
+    counters = collections.defaultdict(float)
+    for d in a.pmc:
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if "integrate_kernel" in r["Kernel_Name"]:
+                    counters[r["Counter_Name"]] += float(r["Counter_Value"]) / a.launches_per_pass
+    summary = {"tag": a.tag, "kernel": "pt::integrate_kernel", "width": a.width, "height": a.height, "spp": a.spp, "mrr": 8,
+               "counters_per_launch": dict(counters)}
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        summary["hbm_bytes_per_launch_raw"] = (counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024
+        summary["hbm_bytes_per_launch"] = (2 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024
+        summary["algorithmic_bytes"] = a.width * a.height * 56 + 270 * 112
+        summary["note"] = ("FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes; FETCH_SIZE doubled per "
+                           "MI355X_MICROARCH.md (gfx950 reports half of a coalesced streaming read)")
+    if "SQ_INSTS_VALU" in counters and "GRBM_GUI_ACTIVE" in counters:
+        cyc = counters["GRBM_GUI_ACTIVE"] / 8.0
+        summary["valu_issue_utilisation"] = counters["SQ_INSTS_VALU"] * 2.0 / (cyc * 1024.0)
+        summary["shader_clock_cycles"] = cyc
+    json.dump(summary, open(os.path.join(out_dir, f"{a.tag}_pmc_hbm.json"), "w"), indent=1)
+    print(json.dumps(summary)[:800])
+
+
+if __name__ == "__main__":
+    main()
