@@ -26,12 +26,15 @@ namespace pt {
 
 namespace {
 
+#ifndef PT_OCTET_UNROLL
+#define PT_OCTET_UNROLL 4
+#endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 7
 #endif
 constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per workgroup (all LDS below is wave-private)
-constexpr int kOctetQueue = 192;          // (lane, octet) work items the wave can park (drained in rounds of 64)
-constexpr int kPairQueue = 256;           // (lane, triangle) work items the wave can park
+constexpr int kOctetQueue = 128;          // (lane, octet) work items the wave can park (drained in rounds of 64)
+constexpr int kPairQueue = 192;           // (lane, triangle) work items the wave can park
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -216,6 +219,7 @@ struct WaveLds {
     float ray[6][64];              // this segment's rays, readable by every lane
     uint32_t octets[kOctetQueue];  // work items: octet number inside the cluster | lane << 8
     uint32_t pairs[kPairQueue];    // work items: triangle index | lane << 24
+    float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_octets = 0, w_exact_iters = 0;   // wave-uniform, live in SGPRs
@@ -243,6 +247,11 @@ __device__ __forceinline__ uint32_t ordered_bits(float f) {
 }
 __device__ __forceinline__ float from_ordered_bits(uint32_t b) {
     return __uint_as_float(b ^ ((b >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// hides a value from loop-invariant code motion (see the accumulator addresses and the camera ray)
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
 }
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
@@ -336,8 +345,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
                         r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                         r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
                         const float4 *tp = reinterpret_cast<const float4 *>(a.spheres) + off + 36u * (b >> 2) + 4u + 8u * (b & 3u);
-#pragma unroll
-                        for (int t8 = 0; t8 < kOctet; ++t8) {
+#pragma unroll PT_OCTET_UNROLL
+                        for (int t8 = 0; t8 < kOctet; ++t8) {   // 4 records in flight: 8 cost 16 more VGPRs at the kernel's peak
                             const float4 sp = tp[t8];
                             m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << t8) : 0u;
                         }
@@ -412,11 +421,30 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
     const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
     const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
 
-    // The accumulators stay in global memory: a pixel belongs to one lane, only ~1 % of the samples touch them
-    // (material.h:74-77), and seven fewer live VGPRs buy a wave per SIMD.  Adds still happen in pass order.
-    float *const acc_sum = a.sum + 3 * p;
-    float *const acc_sum2 = a.sum2 + 3 * p;
-    int32_t *const acc_count = a.count + p;
+    // The tile's accumulators live in LDS for the whole launch (read once, written once: exactly the algorithmic
+    // 56 B/pixel of HBM traffic).  Keeping them in VGPRs costs a wave per SIMD; read-modify-writing them in HBM at every
+    // emitter hit moved 10x the algorithmic bytes, because each hit touches three sparse cache lines.
+    if (in_image) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lds.acc[k][lane] = a.sum[3 * p + k];
+            lds.acc[3 + k][lane] = a.sum2[3 * p + k];
+        }
+        lds.acc[6][lane] = __int_as_float(a.count[p]);
+    }
+    // Adaptive sampling (main.cpp:118-125) asks, before every pass > 10, whether the variance estimate of all three
+    // channels is below `error`.  That is a pure function of the accumulators, which change only when this pixel's
+    // path reaches an emitter, so the answer is cached in one bit and refreshed there: no per-pass re-reads.
+    auto low_variance = [&](float c0, float c1, float c2, float q0, float q1, float q2, int n) {
+        const float sc = static_cast<float>(n);
+        if (!(sc > 0)) return false;
+        const float mr = c0 / sc, mg_ = c1 / sc, mb = c2 / sc;
+        const float dr = q0 / sc - mr * mr, dg = q1 / sc - mg_ * mg_, db = q2 / sc - mb * mb;
+        return dr < a.error && dg < a.error && db < a.error;
+    };
+    bool lowvar = false;
+    if (in_image) lowvar = low_variance(lds.acc[0][lane], lds.acc[1][lane], lds.acc[2][lane], lds.acc[3][lane], lds.acc[4][lane],
+                                        lds.acc[5][lane], __float_as_int(lds.acc[6][lane]));
     // statistics are wave-level (uniform) counts: they live in SGPRs
     uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_miss = 0;
     WaveStats wst;
@@ -429,15 +457,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
 
     for (int pass = a.pass_begin; pass < a.pass_begin + a.pass_count; ++pass) {
         // Adaptive skip, main.cpp:118-125.
-        bool skip = !in_image;
-        if (pass > 10 && (pass % 4) && in_image) {
-            const float sc = static_cast<float>(*acc_count);
-            if (sc > 0) {
-                const float mr = acc_sum[0] / sc, mg_ = acc_sum[1] / sc, mb = acc_sum[2] / sc;
-                const float dr = acc_sum2[0] / sc - mr * mr, dg = acc_sum2[1] / sc - mg_ * mg_, db = acc_sum2[2] / sc - mb * mb;
-                if (dr < a.error && dg < a.error && db < a.error) skip = true;
-            }
-        }
+        const bool skip = !in_image || (pass > 10 && (pass % 4) && lowvar);
         if (__all(skip)) continue;
 
         // Primary ray, main.cpp:126-129 + Ray ctor ray.h:21-25 (double arithmetic, then narrowed).
@@ -448,8 +468,13 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
             uint32_t w0, w1, w2, w3;
             philox4x32_10(gpix, static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
             const double jx = jitter_double(w0), jy = jitter_double(w1);
-            q.dx = static_cast<float>((x + jx) / a.width - 0.5f);
-            q.dy = static_cast<float>(-(y + jy) / a.height + 0.5f);
+            // x, y are made opaque once per pass so that their int->double conversions (and the doubles of width and
+            // height) are redone here instead of being hoisted out of the pass loop, where they would occupy eight
+            // VGPRs for the whole kernel (the compiler spilled them to scratch: ~1 GB of memory traffic per frame).
+            int xi = x, yi = y, wi = a.width, hi = a.height;
+            asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
+            q.dx = static_cast<float>((xi + jx) / wi - 0.5f);
+            q.dy = static_cast<float>(-(yi + jy) / hi + 0.5f);
             q.dz = 1.0f;
             const float inv = 1.0f / __builtin_sqrtf((q.dx * q.dx + q.dy * q.dy) + (1.0f * 1.0f + 0.0f * 0.0f));
             q.dx = q.dx * inv; q.dy = q.dy * inv; q.dz = q.dz * inv;
@@ -503,9 +528,13 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
                     } else if (kind == 0) {   // emissive, material.h:68-79
                         if (!((q.dx * pl.x + q.dy * pl.y) + q.dz * pl.z > 0)) {
                             const float cr = tr * m0v.x, cg = tg * m0v.y, cb = tb * m0v.z;
-                            acc_sum[0] += cr; acc_sum[1] += cg; acc_sum[2] += cb;
-                            acc_sum2[0] += cr * cr; acc_sum2[1] += cg * cg; acc_sum2[2] += cb * cb;
-                            *acc_count += 1;
+                            const float n0 = lds.acc[0][lane] + cr, n1 = lds.acc[1][lane] + cg, n2 = lds.acc[2][lane] + cb;
+                            const float p0 = lds.acc[3][lane] + cr * cr, p1 = lds.acc[4][lane] + cg * cg, p2 = lds.acc[5][lane] + cb * cb;
+                            const int nn = __float_as_int(lds.acc[6][lane]) + 1;
+                            lds.acc[0][lane] = n0; lds.acc[1][lane] = n1; lds.acc[2][lane] = n2;
+                            lds.acc[3][lane] = p0; lds.acc[4][lane] = p1; lds.acc[5][lane] = p2;
+                            lds.acc[6][lane] = __int_as_float(nn);
+                            lowvar = low_variance(n0, n1, n2, p0, p1, p2, nn);
                             contributed = true;
                         }
                         depth = mrr;
@@ -541,6 +570,15 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
         }
     }
 
+    if (in_image) {
+        const size_t pe = static_cast<size_t>(y - a.row_begin) * a.width + x;   // recomputed: p would be spilled across the kernel
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a.sum[3 * pe + k] = lds.acc[k][lane];
+            a.sum2[3 * pe + k] = lds.acc[3 + k][lane];
+        }
+        a.count[pe] = __float_as_int(lds.acc[6][lane]);
+    }
     if (a.stats && lane == 0) {
         atomicAdd(&a.stats[0], static_cast<unsigned long long>(n_traced));
         atomicAdd(&a.stats[1], static_cast<unsigned long long>(n_segments));

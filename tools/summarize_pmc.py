@@ -18,6 +18,12 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(files):
+    if not files:
+        raise SystemExit("no rocprofv3 csv found")
+    return max(files, key=os.path.getmtime)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
@@ -31,11 +37,12 @@ def main():
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     if a.kernel_trace:
-        f = glob.glob(os.path.join(a.kernel_trace, "*", "*_kernel_stats.csv"))[0]
+        f = newest(glob.glob(os.path.join(a.kernel_trace, "*", "*_kernel_stats.csv")))
         shutil.copy(f, os.path.join(out_dir, f"{a.tag}_kernel_stats.csv"))
     counters = collections.defaultdict(float)
     for d in a.pmc:
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        # gpurun merges every call's output into the same local directory: only the newest run counts
+        for f in [newest(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")))]:
             for r in csv.DictReader(open(f)):
                 if "integrate_kernel" in r["Kernel_Name"]:
                     counters[r["Counter_Name"]] += float(r["Counter_Value"]) / a.launches_per_pass
