@@ -89,6 +89,11 @@ int pt_scene_load_obj(const char *model_dir, const char *model_name, int device,
 int pt_scene_create(const float *triangles, const int32_t *triangle_material, int32_t n_triangles,
                     const float *materials, int32_t n_materials, int device, pt_scene **out);
 
+/* -SKYBOX (config.h:26, scene.cpp:20-22): load a 24-bit BMP with bitmap_image::load_bitmap's checks
+ * (bitmap_image.hpp:1508-1603) as the scene's skybox; rays that hit nothing then add its bilinear sample to the
+ * accumulators (scene.cpp:126-154).  NULL or "" removes the skybox.  Not to be called while a render is in flight. */
+int pt_scene_set_skybox_bmp(pt_scene *scene, const char *path);
+
 int pt_scene_counts(const pt_scene *scene, int32_t *n_triangles, int32_t *n_materials);
 int pt_scene_get_triangles(const pt_scene *scene, float *triangles, int32_t *triangle_material);
 int pt_scene_get_materials(const pt_scene *scene, float *materials);

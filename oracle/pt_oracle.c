@@ -78,6 +78,8 @@ typedef struct {
     int n_tri;
     orc_material *mat;
     int n_mat;
+    unsigned char *sky;          /* skybox_ (scene.h:15): BGR bytes, top-down rows, no padding; NULL = no skybox */
+    int sky_w, sky_h;
 } orc_scene;
 
 typedef struct {
@@ -214,6 +216,52 @@ static void portable_sincosf(float a, float *s_out, float *c_out) {
     *c_out = (float)c;
 }
 
+/* Portable atan / atan2 / acos for the skybox lookup (scene.cpp:127-128): double +,-,*,/,sqrt only.
+ * atan follows the classic argument reduction to [0, 7/16] around 0.5, 1, 1.5, inf with an odd polynomial. */
+static double portable_atan_pos(double x) {       /* x >= 0, finite or +inf */
+    static const double hi[4] = { 4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00 };
+    static const double lo[4] = { 2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17 };
+    int id;
+    if (x < 0.4375) id = -1;
+    else if (x < 1.1875) { if (x < 0.6875) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); } else { id = 1; x = (x - 1.0) / (x + 1.0); } }
+    else if (x < 2.4375) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); }
+    else { id = 3; x = -1.0 / x; }
+    const double z = x * x, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02
+                    + w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02
+                    + w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    if (id < 0) return x - x * (s1 + s2);
+    return hi[id] - ((x * (s1 + s2) - lo[id]) - x);
+}
+static float portable_atan2f(float yf, float xf) {
+    const double y = (double)yf, x = (double)xf;
+    if (y != y || x != x) return NAN;
+    const double pi = 3.14159265358979311600e+00, pi_2 = 1.57079632679489655800e+00;
+    const double ay = y < 0 ? -y : y, ax = x < 0 ? -x : x;
+    double r;
+    if (ay == 0.0) r = (x < 0 || (x == 0 && signbit(xf))) ? pi : 0.0;
+    else if (ax == 0.0) r = pi_2;
+    else {
+        const double t = portable_atan_pos(ay / ax);
+        r = x < 0 ? pi - t : t;
+    }
+    return (float)((y < 0 || (y == 0 && signbit(yf))) ? -r : r);
+}
+static float portable_acosf(float vf) {
+    const double v = (double)vf;
+    const double s = sqrt((1.0 - v) * (1.0 + v));       /* NaN for |v| > 1, like acosf */
+    if (s != s) return NAN;
+    const double pi = 3.14159265358979311600e+00, pi_2 = 1.57079632679489655800e+00;
+    double r;
+    if (v == 0.0) r = pi_2;
+    else {
+        const double t = portable_atan_pos(s / (v < 0 ? -v : v));
+        r = v < 0 ? pi - t : t;
+    }
+    return (float)r;
+}
+
 /* ------------------------------------------------------------------ */
 /* Scene set-up                                                         */
 /* ------------------------------------------------------------------ */
@@ -255,7 +303,37 @@ static void mat_build(orc_material *m) {
 
 void orc_scene_free(orc_scene *s) {
     if (!s) return;
-    free(s->tri); free(s->mat); free(s);
+    free(s->tri); free(s->mat); free(s->sky); free(s);
+}
+
+/* bitmap_image(filename) -> load_bitmap (bitmap_image.hpp:1508-1603), as Scene's constructor uses it for -SKYBOX
+ * (scene.cpp:20-22).  Returns 0 on success; on any of the reference's load errors the scene keeps no skybox
+ * (the reference would go on with a 0x0 image and divide by zero at the first miss). */
+int orc_scene_set_skybox(orc_scene *s, const char *path) {
+    free(s->sky); s->sky = NULL; s->sky_w = s->sky_h = 0;
+    if (!path || !*path) return 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return 1;
+    unsigned char h[54];
+    if (fread(h, 1, 54, f) != 54) { fclose(f); return 2; }
+    uint16_t type, bit_count; uint32_t bih_size, w, hgt;
+    memcpy(&type, h, 2); memcpy(&bih_size, h + 14, 4); memcpy(&w, h + 18, 4); memcpy(&hgt, h + 22, 4); memcpy(&bit_count, h + 28, 2);
+    if (type != 19778 || bit_count != 24 || bih_size != 40) { fclose(f); return 3; }
+    const unsigned pad = (4 - ((3 * w) % 4)) % 4;
+    fseek(f, 0, SEEK_END);
+    const size_t physical = (size_t)ftell(f);
+    const size_t logical = (size_t)hgt * w * 3 + (size_t)hgt * pad + 40 + 14;
+    if (physical != logical || w == 0 || hgt == 0) { fclose(f); return 4; }
+    fseek(f, 54, SEEK_SET);
+    s->sky = (unsigned char *)malloc((size_t)w * hgt * 3);
+    unsigned char padbuf[4];
+    for (uint32_t i = 0; i < hgt; ++i) {                                  /* rows are stored bottom-up */
+        if (fread(s->sky + (size_t)(hgt - i - 1) * w * 3, 1, (size_t)w * 3, f) != (size_t)w * 3) { fclose(f); free(s->sky); s->sky = NULL; return 5; }
+        if (pad && fread(padbuf, 1, pad, f) != pad) { fclose(f); free(s->sky); s->sky = NULL; return 5; }
+    }
+    fclose(f);
+    s->sky_w = (int)w; s->sky_h = (int)hgt;
+    return 0;
 }
 
 /* Build from flat arrays: tri14 = plane[4], v0,v1,v2[9], square[1]; mats = Kd,Ke,Ks,Ns (10 floats). */
@@ -517,7 +595,39 @@ static void trace_segment(orc_ctx *cx, orc_ray *r) {
         if (stage == 4) cur = i;
     }
     cx->st->segments++;
-    if (cur < 0) { cx->st->misses++; r->depth = mrr; return; }            /* scene.cpp:125,155 */
+    if (cur < 0) {                                                          /* scene.cpp:125-156 */
+        cx->st->misses++;
+        if (sc->sky) {
+            const float pi = 3.141593f;
+            float ac, at;
+            if (cx->pr->trig_policy == ORC_TRIG_LIBM) { ac = acosf(r->d[1]); at = atan2f(r->d[2], -r->d[0]); }
+            else { ac = portable_acosf(r->d[1]); at = portable_atan2f(r->d[2], -r->d[0]); }
+            const float theta = ac / pi;
+            const float phi = at / pi / 2 + 0.5f;
+            const float x = phi * (float)(unsigned)sc->sky_w, y = theta * (float)(unsigned)sc->sky_h;
+            /* static_cast<unsigned>(float): undefined for NaN / out of range in the reference; here such values,
+             * and a coordinate that lands on the last row/column + 1, are clamped into the image */
+            unsigned x1 = (x >= 0.0f) ? (x < 4294967040.0f ? (unsigned)x : 0xFFFFFFFFu) : 0u;
+            unsigned y1 = (y >= 0.0f) ? (y < 4294967040.0f ? (unsigned)y : 0xFFFFFFFFu) : 0u;
+            if (x1 > (unsigned)sc->sky_w - 1u) x1 = (unsigned)sc->sky_w - 1u;
+            if (y1 > (unsigned)sc->sky_h - 1u) y1 = (unsigned)sc->sky_h - 1u;
+            const unsigned x2 = (x1 + 1) % (unsigned)sc->sky_w, y2 = (y1 + 1) % (unsigned)sc->sky_h;
+            const unsigned char *t1 = sc->sky + ((size_t)y1 * sc->sky_w + x1) * 3, *t2 = sc->sky + ((size_t)y1 * sc->sky_w + x2) * 3;
+            const unsigned char *t3 = sc->sky + ((size_t)y2 * sc->sky_w + x1) * 3, *t4 = sc->sky + ((size_t)y2 * sc->sky_w + x2) * 3;
+            const float ax = 1 - x + (float)x1, ay = 1 - y + (float)y1;   /* the weights of scene.cpp:146-149, as written */
+            for (int k = 0; k < 3; ++k) {                                   /* k: r,g,b = bytes 2,1,0 */
+                const float c1 = (float)t1[2 - k], c2 = (float)t2[2 - k], c3 = (float)t3[2 - k], c4 = (float)t4[2 - k];
+                const float c12 = c1 * (1.0f - ax) + c2 * ax;             /* glm::mix(x, y, a) = x*(1-a) + y*a */
+                const float c34 = c3 * (1.0f - ax) + c4 * ax;
+                const float c = (c12 * (1.0f - ay) + c34 * ay) / 256.f;
+                cx->sum[k] += c; cx->sum2[k] += c * c;
+            }
+            ++*cx->count;
+            cx->st->contributing++;
+        }
+        r->depth = mrr;
+        return;
+    }
     const orc_triangle *t = &sc->tri[cur];
     const float P[3] = { r->o[0] + r->d[0] * distance, r->o[1] + r->d[1] * distance, r->o[2] + r->d[2] * distance };
     const float *Nn = t->plane;
@@ -748,6 +858,12 @@ void orc_probe_minstd(uint32_t seed, int n, uint32_t *raw, float *unit, double *
 void orc_probe_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
 float orc_probe_unit_float(uint32_t w) { return u32_to_unit_float(w); }
 double orc_probe_jitter(uint32_t w) { return u32_to_jitter(w); }
+void orc_probe_acos_atan2(const float *v, const float *y, const float *x, int n, int policy, float *ac, float *at) {
+    for (int i = 0; i < n; ++i) {
+        if (policy == ORC_TRIG_LIBM) { ac[i] = acosf(v[i]); at[i] = atan2f(y[i], x[i]); }
+        else { ac[i] = portable_acosf(v[i]); at[i] = portable_atan2f(y[i], x[i]); }
+    }
+}
 void orc_probe_sincos(const float *a, int n, int policy, float *s, float *c) {
     for (int i = 0; i < n; ++i) {
         if (policy == ORC_TRIG_LIBM) { s[i] = sinf(a[i]); c[i] = cosf(a[i]); }

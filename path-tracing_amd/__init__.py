@@ -24,7 +24,7 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT
 # every symbol include/pt_hip.h declares
 ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
                "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_trace_rays_host",
-               "pt_scene_cull_tables", "pt_resolve",
+               "pt_scene_cull_tables", "pt_scene_set_skybox_bmp", "pt_resolve",
                "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
 
 
@@ -79,6 +79,7 @@ def lib():
         L.pt_render_host.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.POINTER(RenderStats)]
         L.pt_trace_rays_host.argtypes = [vp, C.c_int32, fp, fp, C.c_float, ip, fp]
         L.pt_scene_cull_tables.argtypes = [vp, C.c_float, ip, fp, fp, fp, fp]
+        L.pt_scene_set_skybox_bmp.argtypes = [vp, C.c_char_p]
         L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
         L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.pt_last_error.restype = C.c_char_p
@@ -154,6 +155,10 @@ class Scene:
         st = RenderStats()
         _check(lib().pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None))
         return s, s2, c, st.as_dict()
+
+    def set_skybox(self, path):
+        """-SKYBOX: a 24-bit BMP sampled by rays that hit nothing (scene.cpp:126-154); None or "" removes it."""
+        _check(lib().pt_scene_set_skybox_bmp(self._h, (path or "").encode()))
 
     def cull_tables(self, eps=1e-4):
         """The culling hierarchy for `eps` (diagnostics): dict of clusters, spheres, bary records, constants."""

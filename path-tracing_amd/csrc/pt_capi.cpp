@@ -34,6 +34,9 @@ struct pt_scene {
     pt::ExactRec *d_exact = nullptr;
     pt::MatRec *d_mats = nullptr;
     unsigned long long *d_stats = nullptr;
+    std::vector<uint8_t> sky;   // skybox texels (B,G,R; top-down rows; no padding), empty = none
+    int sky_w = 0, sky_h = 0;
+    uint8_t *d_sky = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -176,6 +179,65 @@ int pt_scene_create(const float *triangles, const int32_t *triangle_material, in
     return finish_scene(s, device, out);
 }
 
+int pt_scene_set_skybox_bmp(pt_scene *scene, const char *path) {
+    if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
+    std::vector<uint8_t> texels;
+    int w = 0, h = 0;
+    if (path && *path) {
+        // bitmap_image(filename) -> load_bitmap(), bitmap_image.hpp:1508-1603: the same checks, reported instead of printed
+        FILE *f = std::fopen(path, "rb");
+        if (!f) return fail(PT_ERR_IO, std::string("skybox: cannot open ") + path);
+        uint8_t hdr[54];
+        const bool got = std::fread(hdr, 1, 54, f) == 54;
+        auto u16 = [&](int at) { return static_cast<uint32_t>(hdr[at]) | (static_cast<uint32_t>(hdr[at + 1]) << 8); };
+        auto u32 = [&](int at) { return u16(at) | (u16(at + 2) << 16); };
+        std::string why;
+        if (!got) why = "file shorter than its headers";
+        else if (u16(0) != 19778) why = "invalid type value " + std::to_string(u16(0)) + " expected 19778";
+        else if (u16(28) != 24) why = "invalid bit depth " + std::to_string(u16(28)) + " expected 24";
+        else if (u32(14) != 40) why = "invalid BIH size " + std::to_string(u32(14)) + " expected 40";
+        if (why.empty()) {
+            const uint32_t uw = u32(18), uh = u32(22);
+            const uint32_t pad = (4u - (3u * uw) % 4u) % 4u;
+            std::fseek(f, 0, SEEK_END);
+            const size_t physical = static_cast<size_t>(std::ftell(f));
+            const size_t logical = static_cast<size_t>(uh) * uw * 3 + static_cast<size_t>(uh) * pad + 54;
+            if (physical != logical || uw == 0 || uh == 0) {
+                why = "mismatch between logical (" + std::to_string(logical) + ") and physical (" + std::to_string(physical) + ") sizes";
+            } else {
+                texels.resize(static_cast<size_t>(uw) * uh * 3);
+                std::fseek(f, 54, SEEK_SET);
+                uint8_t padbuf[4];
+                for (uint32_t i = 0; i < uh && why.empty(); ++i) {   // rows are stored bottom-up
+                    if (std::fread(&texels[static_cast<size_t>(uh - i - 1) * uw * 3], 1, static_cast<size_t>(uw) * 3, f) != static_cast<size_t>(uw) * 3 ||
+                        (pad && std::fread(padbuf, 1, pad, f) != pad))
+                        why = "short read";
+                }
+                w = static_cast<int>(uw);
+                h = static_cast<int>(uh);
+            }
+        }
+        std::fclose(f);
+        if (!why.empty()) return fail(PT_ERR_PARSE, std::string("skybox ") + path + ": " + why);
+    }
+    if (scene->device >= 0) {
+        PT_HIP_TRY(hipSetDevice(scene->device));
+        PT_HIP_TRY(hipDeviceSynchronize());
+        if (scene->d_sky) {
+            (void)hipFree(scene->d_sky);
+            scene->d_sky = nullptr;
+        }
+        if (!texels.empty()) {
+            PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scene->d_sky), texels.size() + 64));
+            PT_HIP_TRY(hipMemcpy(scene->d_sky, texels.data(), texels.size(), hipMemcpyHostToDevice));
+        }
+    }
+    scene->sky.swap(texels);
+    scene->sky_w = w;
+    scene->sky_h = h;
+    return PT_OK;
+}
+
 int pt_scene_counts(const pt_scene *scene, int32_t *n_triangles, int32_t *n_materials) {
     if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
     if (n_triangles) *n_triangles = scene->host.n_tri();
@@ -206,6 +268,7 @@ void pt_scene_destroy(pt_scene *s) {
         if (s->d_exact) (void)hipFree(s->d_exact);
         if (s->d_mats) (void)hipFree(s->d_mats);
         if (s->d_stats) (void)hipFree(s->d_stats);
+        if (s->d_sky) (void)hipFree(s->d_sky);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
     }
@@ -228,6 +291,9 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     a.bary = scene->cull.bary;
     a.exact = scene->d_exact;
     a.mats = scene->d_mats;
+    a.sky = scene->d_sky;
+    a.sky_w = scene->sky_w;
+    a.sky_h = scene->sky_h;
     a.sum = d_sum;
     a.sum2 = d_sum2;
     a.count = d_count;

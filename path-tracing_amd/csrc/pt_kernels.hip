@@ -83,6 +83,57 @@ __device__ __forceinline__ void portable_sincos(float a, float &s_out, float &c_
     c_out = static_cast<float>(c);
 }
 
+// Portable atan / atan2 / acos for the skybox lookup (scene.cpp:127-128): double +,-,*,/,sqrt only, the same
+// sequence as the CPU oracle's, so that texel coordinates agree bit for bit.
+__device__ __forceinline__ double portable_atan_pos(double x) {   // x >= 0, finite or +inf
+    int id;
+    double hi = 0.0, lo = 0.0;
+    if (x < 0.4375) {
+        id = -1;
+    } else if (x < 1.1875) {
+        if (x < 0.6875) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+        else { id = 1; x = (x - 1.0) / (x + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+    } else if (x < 2.4375) {
+        id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17;
+    } else {
+        id = 3; x = -1.0 / x; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17;
+    }
+    const double z = x * x, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02
+                    + w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02
+                    + w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    if (id < 0) return x - x * (s1 + s2);
+    return hi - ((x * (s1 + s2) - lo) - x);
+}
+__device__ __forceinline__ float portable_atan2f(float yf, float xf) {
+    const double y = static_cast<double>(yf), x = static_cast<double>(xf);
+    if (y != y || x != x) return __builtin_nanf("");
+    const double pi = 3.14159265358979311600e+00, pi_2 = 1.57079632679489655800e+00;
+    const double ay = y < 0 ? -y : y, ax = x < 0 ? -x : x;
+    double r;
+    if (ay == 0.0) r = (x < 0 || (x == 0 && __builtin_signbit(xf))) ? pi : 0.0;
+    else if (ax == 0.0) r = pi_2;
+    else {
+        const double t = portable_atan_pos(ay / ax);
+        r = x < 0 ? pi - t : t;
+    }
+    return static_cast<float>((y < 0 || (y == 0 && __builtin_signbit(yf))) ? -r : r);
+}
+__device__ __forceinline__ float portable_acosf(float vf) {
+    const double v = static_cast<double>(vf);
+    const double s = __builtin_sqrt((1.0 - v) * (1.0 + v));   // NaN for |v| > 1, like acosf
+    if (s != s) return __builtin_nanf("");
+    const double pi = 3.14159265358979311600e+00, pi_2 = 1.57079632679489655800e+00;
+    double r;
+    if (v == 0.0) r = pi_2;
+    else {
+        const double t = portable_atan_pos(s / (v < 0 ? -v : v));
+        r = v < 0 ? pi - t : t;
+    }
+    return static_cast<float>(r);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 1. CULL: may only answer "this triangle cannot be accepted by Triangle::Intersect for this ray".
 // ---------------------------------------------------------------------------------------------------------------
@@ -411,7 +462,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
 // ---------------------------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+// SKY = the scene has a skybox (scene.cpp:126-154).  A separate instantiation: the lookup's double arithmetic raises
+// the register peak, and the no-skybox kernel (every BASELINE configuration) should not pay for it.
+template <bool SKY>
+__global__ __launch_bounds__(kBlock, SKY ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
     __shared__ WaveLds lds;   // one wave per workgroup: everything in it is wave-private
 
     const int lane = threadIdx.x;
@@ -500,6 +554,39 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void integrate_kernel(co
             bool contributed = false;
             if (valid) {
                 if (hit < 0) {
+                    if (SKY) {   // skybox miss shader, scene.cpp:126-154 (note: the path throughput is NOT applied)
+                        const float pi = 3.141593f;
+                        const float theta = portable_acosf(q.dy) / pi;
+                        const float phi = portable_atan2f(q.dz, -q.dx) / pi / 2 + 0.5f;
+                        const uint32_t sw = static_cast<uint32_t>(a.sky_w), sh = static_cast<uint32_t>(a.sky_h);
+                        const float sx = phi * static_cast<float>(sw), sy = theta * static_cast<float>(sh);
+                        // float -> unsigned is undefined for NaN / out of range in the reference; clamp into the image
+                        uint32_t x1 = (sx >= 0.0f) ? (sx < 4294967040.0f ? static_cast<uint32_t>(sx) : 0xFFFFFFFFu) : 0u;
+                        uint32_t y1 = (sy >= 0.0f) ? (sy < 4294967040.0f ? static_cast<uint32_t>(sy) : 0xFFFFFFFFu) : 0u;
+                        x1 = min(x1, sw - 1u);
+                        y1 = min(y1, sh - 1u);
+                        const uint32_t x2 = (x1 + 1u) % sw, y2 = (y1 + 1u) % sh;
+                        const uint8_t *t1 = a.sky + (static_cast<size_t>(y1) * sw + x1) * 3, *t2 = a.sky + (static_cast<size_t>(y1) * sw + x2) * 3;
+                        const uint8_t *t3 = a.sky + (static_cast<size_t>(y2) * sw + x1) * 3, *t4 = a.sky + (static_cast<size_t>(y2) * sw + x2) * 3;
+                        const float ax = 1 - sx + static_cast<float>(x1), ay = 1 - sy + static_cast<float>(y1);
+                        float c[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {   // r,g,b = bytes 2,1,0
+                            const float c1 = static_cast<float>(t1[2 - k]), c2 = static_cast<float>(t2[2 - k]);
+                            const float c3 = static_cast<float>(t3[2 - k]), c4 = static_cast<float>(t4[2 - k]);
+                            const float c12 = c1 * (1.0f - ax) + c2 * ax;   // glm::mix(x, y, a) = x*(1-a) + y*a
+                            const float c34 = c3 * (1.0f - ax) + c4 * ax;
+                            c[k] = (c12 * (1.0f - ay) + c34 * ay) / 256.f;
+                        }
+                        const float n0 = lds.acc[0][lane] + c[0], n1 = lds.acc[1][lane] + c[1], n2 = lds.acc[2][lane] + c[2];
+                        const float p0 = lds.acc[3][lane] + c[0] * c[0], p1 = lds.acc[4][lane] + c[1] * c[1], p2 = lds.acc[5][lane] + c[2] * c[2];
+                        const int nn = __float_as_int(lds.acc[6][lane]) + 1;
+                        lds.acc[0][lane] = n0; lds.acc[1][lane] = n1; lds.acc[2][lane] = n2;
+                        lds.acc[3][lane] = p0; lds.acc[4][lane] = p1; lds.acc[5][lane] = p2;
+                        lds.acc[6][lane] = __int_as_float(nn);
+                        lowvar = low_variance(n0, n1, n2, p0, p1, p2, nn);
+                        contributed = true;
+                    }
                     depth = mrr;   // MakeInvalid
                 } else {
                     const ExactRec *__restrict__ rec = a.exact + hit;
@@ -632,7 +719,10 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     if (rows <= 0 || args.width <= 0) return hipSuccess;
     const int blocks_y = (rows + 7) / 8;
     const unsigned grid = static_cast<unsigned>(args.blocks_x) * static_cast<unsigned>(blocks_y);
-    hipLaunchKernelGGL(integrate_kernel, dim3(grid), dim3(kBlock), 0, stream, args);
+    if (args.sky)
+        hipLaunchKernelGGL(integrate_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, args);
+    else
+        hipLaunchKernelGGL(integrate_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -16,6 +16,8 @@ struct RenderArgs {
     const CullRec *bary;
     const ExactRec *exact;    // n_tri
     const MatRec *mats;
+    const uint8_t *sky;       // skybox texels (B,G,R bytes, top-down rows) or nullptr
+    int32_t sky_w, sky_h;
     float *sum, *sum2;        // row band, 3 floats per pixel
     int32_t *count;
     unsigned long long *stats;   // 8 counters or nullptr

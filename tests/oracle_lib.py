@@ -66,6 +66,8 @@ def lib():
         L.orc_probe_unit_float.argtypes = [C.c_uint32]
         L.orc_probe_jitter.restype = C.c_double
         L.orc_probe_jitter.argtypes = [C.c_uint32]
+        L.orc_scene_set_skybox.argtypes = [vp, C.c_char_p]
+        L.orc_probe_acos_atan2.argtypes = [fp, fp, fp, C.c_int, C.c_int, fp, fp]
         L.orc_probe_sincos.argtypes = [fp, C.c_int, C.c_int, fp, fp]
         L.orc_probe_intersect.argtypes = [vp, C.c_int, fp, fp, C.c_float, C.c_float, fp]
         _lib = L
@@ -124,6 +126,11 @@ class Scene:
         t = C.c_float()
         i = lib().orc_closest_hit(self.h, _fp(o), _fp(d), eps, C.byref(t))
         return i, t.value
+
+    def set_skybox(self, path):
+        rc = lib().orc_scene_set_skybox(self.h, (path or "").encode())
+        if rc != 0:
+            raise RuntimeError(f"oracle: skybox could not be loaded ({rc})")
 
     def closest_hits(self, origins, directions, eps=1e-4, threads=0):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
