@@ -133,7 +133,8 @@ int pt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t 
 
 /* The culling hierarchy built for `eps` (host side; works on device < 0 scenes).  counts[4] = clusters, sphere
  * records, barycentric records, triangles handled by the barycentric class.  Pass NULL tables to query counts only.
- * clusters: 8 words each (centre[3], r2, first_tri, n_tri, kind, data_off -- the last four as uint32 bit patterns);
+ * clusters: 16 words each (centre[3], r2, then as uint32 bit patterns first_tri, n_tri, kind, data_off, n_levels,
+ * level_off[7]: the sphere tree of a small-triangle cluster, see path-tracing_amd/csrc/pt_scene.hpp);
  * spheres: 4 floats each (centre[3], r2); bary: 12 floats each; constants: k1, k2, a_max, m0, t_guard. */
 int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary,
                          float *constants);

@@ -164,14 +164,16 @@ class Scene:
         """The culling hierarchy for `eps` (diagnostics): dict of clusters, spheres, bary records, constants."""
         counts = np.zeros(4, np.int32)
         _check(lib().pt_scene_cull_tables(self._h, eps, _ip(counts), None, None, None, None))
-        cl = np.zeros((counts[0], 8), np.float32)
+        cl = np.zeros((counts[0], 16), np.float32)
         sp = np.zeros((counts[1], 4), np.float32)
         ba = np.zeros((counts[2], 12), np.float32)
         k = np.zeros(5, np.float32)
         _check(lib().pt_scene_cull_tables(self._h, eps, _ip(counts), _fp(cl), _fp(sp), _fp(ba), _fp(k)))
-        meta = cl[:, 4:8].view(np.uint32)
+        meta = cl[:, 4:16].view(np.uint32)
         return {"cluster_sphere": cl[:, :4], "first_tri": meta[:, 0].astype(int), "n_tri": meta[:, 1].astype(int),
-                "kind": meta[:, 2].astype(int), "data_off": meta[:, 3].astype(int), "spheres": sp, "bary": ba,
+                "kind": meta[:, 2].astype(int), "data_off": meta[:, 3].astype(int), "n_levels": meta[:, 4].astype(int),
+                "level_off": np.concatenate([np.zeros((len(cl), 1), int), meta[:, 5:12].astype(int)], 1),
+                "spheres": sp, "bary": ba,
                 "constants": dict(zip(["k1", "k2", "a_max", "m0", "t_guard"], k.tolist())), "n_large": int(counts[3])}
 
     def trace_rays(self, origins, directions, eps=1e-4):

@@ -18,6 +18,8 @@
 // and v_rcp_f32, and step 1 cannot change a result (DESIGN.md "Culling: why it cannot reject a hit").
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pt_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -30,11 +32,15 @@ namespace {
 #define PT_OCTET_UNROLL 4
 #endif
 #ifndef PT_WAVES_PER_SIMD
-#define PT_WAVES_PER_SIMD 7
+#define PT_WAVES_PER_SIMD 6
 #endif
 constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per workgroup (all LDS below is wave-private)
-constexpr int kOctetQueue = 128;          // (lane, octet) work items the wave can park (drained in rounds of 64)
-constexpr int kPairQueue = 192;           // (lane, triangle) work items the wave can park
+// Capacity of the two wave-private work queues.  Small scenes (Tor.obj) keep them small so that 5 KB of LDS per wave
+// leaves room for 6+ waves per SIMD; scenes with thousands of triangles get deep queues (fuller rounds) and pay with
+// occupancy, which matters less there.
+constexpr int kBigSceneTriangles = 2048;
+struct SmallQueues { static constexpr int kNodeStack = 96, kPairQueue = 144; };
+struct BigQueues { static constexpr int kNodeStack = 832, kPairQueue = 512; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -265,11 +271,15 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // Closest hit of every lane's ray: Scene::TraceRay's loop (scene.cpp:114-120) for one wave.  Wave-uniform control
 // flow: all 64 lanes must call it together; lanes with valid == false take part in the shared work only.
 // ---------------------------------------------------------------------------------------------------------------
+template <class Q>
 struct WaveLds {
+    static constexpr int kNodeStack = Q::kNodeStack, kPairQueue = Q::kPairQueue;
     unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
     float ray[6][64];              // this segment's rays, readable by every lane
-    uint32_t octets[kOctetQueue];  // work items: octet number inside the cluster | lane << 8
-    uint32_t pairs[kPairQueue];    // work items: triangle index | lane << 24
+    uint32_t nodes[kNodeStack + 64];// LIFO of tree nodes to expand: lane << 26 | level << 23 | node index within its level
+    uint32_t pairs[kPairQueue];    // (ray, triangle) work items: triangle index | lane << 24
+    uint32_t level_off[kMaxLevels];// sphere offset of each level of the cluster being walked
+    uint32_t level_cnt[kMaxLevels];// number of real nodes of each level
     float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
 };
 struct WaveStats {
@@ -309,8 +319,10 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-__device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, const Ray &q, bool valid, int lane,
+template <class Lds>
+__device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray &q, bool valid, int lane,
                                             float eps, float &best, int &hit, WaveStats &st) {
+    constexpr uint32_t kNodeStack = Lds::kNodeStack, kPairQueue = Lds::kPairQueue;
     ++st.w_segments;
     PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
     lds.best[lane] = ~0ull;
@@ -343,6 +355,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
         }
     };
     // Append one pair per set bit of `bits` (bit j = triangle tri0 + j of ray `src`), compacting over the wave.
+    // The caller guarantees room for every bit (see `commit` below and the large-triangle branch).
     auto push_pairs = [&](uint32_t bits, uint32_t tri0, uint32_t src) {
         while (__any(bits != 0)) {
             const bool has = bits != 0;
@@ -353,8 +366,29 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
                 lds.pairs[n_pairs + lanes_below(ball)] = (tri0 + j) | (src << 24);
             }
             n_pairs += __builtin_popcountll(ball);
-            wave_sync();
-            if (n_pairs > kPairQueue - 64) drain_pairs(63);   // keeps whole rounds only
+        }
+        wave_sync();
+    };
+    // wave-wide sum of a small per-lane count (< 64): one ballot per bit instead of a shuffle tree
+    auto wave_sum = [&](uint32_t v, int bits) {
+        uint32_t total = 0;
+        for (int b = 0; b < bits; ++b) total += static_cast<uint32_t>(__builtin_popcountll(__ballot((v >> b) & 1u))) << b;
+        return total;
+    };
+    // push_pairs for masks of any width: makes room first, and slices the mask if one batch could exceed the queue
+    auto push_pairs_any = [&](uint32_t bits, uint32_t tri0, uint32_t src) {
+        const uint32_t total = wave_sum(__builtin_popcount(bits), 6);
+        if (total == 0) return;
+        if (n_pairs + total > kPairQueue) drain_pairs(0);
+        if (total <= kPairQueue) {
+            push_pairs(bits, tri0, src);
+            return;
+        }
+        for (uint32_t lo = 0; lo < 32u; lo += 2u) {   // <= 128 pairs per slice
+            const uint32_t part = bits & (3u << lo);
+            if (!__any(part != 0)) continue;
+            if (n_pairs + 128u > kPairQueue) drain_pairs(0);
+            push_pairs(part, tri0, src);
         }
     };
 
@@ -362,75 +396,131 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
     const ConstF clusters = (ConstF)reinterpret_cast<uintptr_t>(a.clusters);
     const ConstF spheres = (ConstF)reinterpret_cast<uintptr_t>(a.spheres);
     const ConstF bary = (ConstF)reinterpret_cast<uintptr_t>(a.bary);
+    constexpr int kDescWords = sizeof(ClusterDesc) / 4;
     for (int cl = 0; cl < a.n_clusters; ++cl) {
-        const ConstF cp = clusters + 8 * cl;
+        const ConstF cp = clusters + kDescWords * cl;
         const bool pc = valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q);
         if (!__any(pc)) continue;
         const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
-        const int n_words = static_cast<int>((n_tri + kChunk - 1) / kChunk);
         if (kind == 0) {
-            // (a) every lane against the cluster's octet spheres (wave-uniform, records in SGPRs)
-            uint32_t omask = 0;
-            for (int w = 0; w < n_words; ++w) {
-                const ConstF sp = spheres + 4 * (static_cast<size_t>(off) + 36u * w);
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const bool po = sphere_keep(sp[4 * o], sp[4 * o + 1], sp[4 * o + 2], sp[4 * o + 3], q);
-                    omask |= po ? (1u << (4 * w + o)) : 0u;
-                }
+            // ---- small triangles: an 8-ary tree of bounding spheres, walked with a wave-wide LIFO of (ray, node) items
+            const uint32_t n_levels = ((ConstU)cp)[8];
+            const uint32_t top = n_levels - 1;
+            if (lane < static_cast<int>(n_levels)) {
+                lds.level_off[lane] = lane == 0 ? 0u : a.clusters[cl].level_off[lane - 1];
+                lds.level_cnt[lane] = (n_tri + (1u << (3 * lane)) - 1u) >> (3 * lane);
             }
-            omask = pc ? omask : 0u;
-            PT_STAMP(st, 1);   // cluster + octet sphere tests
-            // (b) the surviving (lane, octet) items, spread evenly over the lanes: 8 triangle spheres each
-            uint32_t n_items = 0;
-            auto drain_octets = [&]() {
-                for (uint32_t i0 = 0; i0 < n_items; i0 += 64) {
-                    ++st.w_octets;
-                    const uint32_t i = i0 + lane;
-                    uint32_t m8 = 0, src = 0, tri0 = 0;
-                    if (i < n_items) {
-                        const uint32_t e = lds.octets[i];
-                        src = e >> 8;
-                        const uint32_t b = e & 31u;
-                        Ray r;
-                        r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
-                        r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
-                        const float4 *tp = reinterpret_cast<const float4 *>(a.spheres) + off + 36u * (b >> 2) + 4u + 8u * (b & 3u);
-#pragma unroll PT_OCTET_UNROLL
-                        for (int t8 = 0; t8 < kOctet; ++t8) {   // 4 records in flight: 8 cost 16 more VGPRs at the kernel's peak
-                            const float4 sp = tp[t8];
-                            m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << t8) : 0u;
-                        }
-                        const uint32_t local = 8u * b;   // first triangle of the octet, relative to the cluster
-                        const uint32_t left = n_tri > local ? n_tri - local : 0u;
-                        m8 &= left >= 8u ? 0xFFu : ((1u << left) - 1u);   // padding spheres are never candidates
-                        tri0 = first_tri + local;
+            wave_sync();
+            // (a) wave-uniform: every lane against the (at most 8) top-level spheres, records in SGPRs
+            const uint32_t top_off = top == 0 ? 0u : ((ConstU)cp)[8 + top];
+            const uint32_t top_cnt = (n_tri + (1u << (3 * top)) - 1u) >> (3 * top);
+            const ConstF tp = spheres + 4 * (static_cast<size_t>(off) + top_off);
+            uint32_t tmask = 0;
+            for (uint32_t j = 0; j < top_cnt; ++j)
+                tmask |= sphere_keep(tp[4 * j], tp[4 * j + 1], tp[4 * j + 2], tp[4 * j + 3], q) ? (1u << j) : 0u;
+            tmask = pc ? tmask : 0u;
+            PT_STAMP(st, 1);   // cluster + top-level sphere tests
+            uint32_t n_nodes = 0;   // wave-uniform fill level of lds.nodes
+            if (top == 0) {
+                push_pairs_any(tmask, first_tri, static_cast<uint32_t>(lane));   // the run has at most 8 triangles
+                tmask = 0;
+            } else {
+                while (__any(tmask != 0)) {   // at most 8 x 64 = 512 items > capacity: drained in the loop below before overflow
+                    const bool has = tmask != 0;
+                    const unsigned long long ball = __ballot(has);
+                    if (n_nodes + __builtin_popcountll(ball) > kNodeStack) break;   // rest is pushed after the stack has drained
+                    if (has) {
+                        const uint32_t j = __builtin_ctz(tmask);
+                        tmask &= tmask - 1;
+                        lds.nodes[n_nodes + lanes_below(ball)] = (static_cast<uint32_t>(lane) << 26) | (top << 23) | j;
                     }
-                    push_pairs(m8, tri0, src);
+                    n_nodes += __builtin_popcountll(ball);
                 }
-                n_items = 0;
-            };
-            uint32_t om = omask;
-            while (__any(om != 0)) {
-                const bool has = om != 0;
-                const unsigned long long ball = __ballot(has);
-                if (has) {
-                    const uint32_t b = __builtin_ctz(om);
-                    om &= om - 1;
-                    lds.octets[n_items + lanes_below(ball)] = b | (static_cast<uint32_t>(lane) << 8);
-                }
-                n_items += __builtin_popcountll(ball);
                 wave_sync();
-                if (n_items > kOctetQueue - 64) drain_octets();
             }
-            drain_octets();
-            PT_STAMP(st, 2);   // balanced octet expansion
+            // (b) lane-balanced expansion: lane l takes the l-th item from the top of the stack, tests the node's 8
+            // children against that item's ray and pushes the survivors (tree nodes back on the stack, triangles as
+            // (ray, triangle) pairs).  A round is committed only for the top k lanes whose children fit.
+            while (n_nodes > 0 || __any(tmask != 0)) {
+                if (n_nodes == 0) {   // top-level items that did not fit earlier
+                    while (__any(tmask != 0)) {
+                        const bool has = tmask != 0;
+                        const unsigned long long ball = __ballot(has);
+                        if (n_nodes + __builtin_popcountll(ball) > kNodeStack) break;
+                        if (has) {
+                            const uint32_t j = __builtin_ctz(tmask);
+                            tmask &= tmask - 1;
+                            lds.nodes[n_nodes + lanes_below(ball)] = (static_cast<uint32_t>(lane) << 26) | (top << 23) | j;
+                        }
+                        n_nodes += __builtin_popcountll(ball);
+                    }
+                    wave_sync();
+                }
+                ++st.w_octets;
+                const uint32_t cnt = min(64u, n_nodes);
+                uint32_t m8 = 0, src = 0, level = 1, child0 = 0;
+                if (static_cast<uint32_t>(lane) < cnt) {
+                    const uint32_t e = lds.nodes[n_nodes - 1 - lane];
+                    src = e >> 26;
+                    level = (e >> 23) & 7u;
+                    child0 = (e & 0x7FFFFFu) * kFan;   // index of the first child within level-1
+                    Ray r;
+                    r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                    r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                    const float4 *cs = reinterpret_cast<const float4 *>(a.spheres) + off + lds.level_off[level - 1] + child0;
+#pragma unroll
+                    for (int c8 = 0; c8 < kFan; ++c8) {
+                        const float4 sp = cs[c8];
+                        m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << c8) : 0u;
+                    }
+                    const uint32_t real = lds.level_cnt[level - 1];   // padding spheres are never children
+                    const uint32_t left = real > child0 ? real - child0 : 0u;
+                    m8 &= left >= 8u ? 0xFFu : ((1u << left) - 1u);
+                }
+                const bool leaf = level == 1;   // children are triangles
+                const uint32_t kids = __builtin_popcount(m8);
+                uint32_t keep = cnt;            // lanes [0, keep) are committed this round
+                const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = wave_sum(leaf ? 0u : kids, 4);
+                if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
+                if (n_pairs + tot_tri > kPairQueue || n_nodes - cnt + tot_node > kNodeStack) {
+                    // Rare: not everything fits.  Commit the longest prefix of lanes (= the top of the stack) whose
+                    // children do; the other items stay where they are.  If not even the top item fits it is committed
+                    // anyway: its (at most 8) children replace it, and since they are one level deeper the stack can
+                    // outgrow kNodeStack by at most 7 per level, which is what the 64 slots of slack are for.
+                    const uint32_t it = wave_inclusive_scan(leaf ? kids : 0u, lane), in = wave_inclusive_scan(leaf ? 0u : kids, lane);
+                    const bool fits = static_cast<uint32_t>(lane) < cnt && n_pairs + it <= kPairQueue &&
+                                      (n_nodes - (lane + 1)) + in <= kNodeStack;
+                    const unsigned long long fb = __ballot(fits);
+                    keep = (fb == ~0ull) ? 64u : static_cast<uint32_t>(__builtin_ctzll(~fb));
+                    if (keep == 0) keep = 1;
+                }
+                if (static_cast<uint32_t>(lane) >= keep) m8 = 0;
+                n_nodes -= keep;
+                wave_sync();
+                // node children back on the stack
+                uint32_t nb = leaf ? 0u : m8;
+                while (__any(nb != 0)) {
+                    const bool has = nb != 0;
+                    const unsigned long long ball = __ballot(has);
+                    if (has) {
+                        const uint32_t c8 = __builtin_ctz(nb);
+                        nb &= nb - 1;
+                        lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | ((level - 1) << 23) | (child0 + c8);
+                    }
+                    n_nodes += __builtin_popcountll(ball);
+                }
+                wave_sync();
+                // triangle children become (ray, triangle) pairs
+                push_pairs(leaf ? m8 : 0u, first_tri + child0, src);
+            }
+            PT_STAMP(st, 2);   // balanced tree walk
         } else {
-            // large triangles: barycentric cull, wave-uniform over the triangles.
+            // ---- large triangles: barycentric cull, wave-uniform over the triangles.
             // The margins go to VGPRs here: a VALU instruction can name only one SGPR, so an SGPR-resident
             // constant next to an SGPR-resident triangle coefficient would cost a v_mov per use.
             float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, t_guard = a.t_guard;
             asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(t_guard));
+            const int n_words = static_cast<int>((n_tri + kChunk - 1) / kChunk);
             for (int w = 0; w < n_words; ++w) {
                 const uint32_t left = n_tri - kChunk * w;
                 const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
@@ -445,7 +535,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
                 m = pc ? m : 0u;
                 m &= left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
                 PT_STAMP(st, 3);   // barycentric cull of the large triangles
-                push_pairs(m, first_tri + kChunk * w, static_cast<uint32_t>(lane));
+                push_pairs_any(m, first_tri + kChunk * w, static_cast<uint32_t>(lane));
                 PT_STAMP(st, 4);   // pair publication
             }
         }
@@ -464,9 +554,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, WaveLds &lds, c
 // ---------------------------------------------------------------------------------------------------------------
 // SKY = the scene has a skybox (scene.cpp:126-154).  A separate instantiation: the lookup's double arithmetic raises
 // the register peak, and the no-skybox kernel (every BASELINE configuration) should not pay for it.
-template <bool SKY>
-__global__ __launch_bounds__(kBlock, SKY ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
-    __shared__ WaveLds lds;   // one wave per workgroup: everything in it is wave-private
+// BIG = deep work queues for scenes with thousands of triangles (see SmallQueues / BigQueues).
+template <bool SKY, bool BIG>
+__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
     const int x = (blockIdx.x % a.blocks_x) * 8 + (lane & 7);
@@ -685,7 +776,7 @@ __global__ __launch_bounds__(kBlock, SKY ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void trace_rays_kernel(const RenderArgs a, const float *__restrict__ origins,
                                                                               const float *__restrict__ directions, int n_rays,
                                                                               int32_t *__restrict__ hit_index, float *__restrict__ hit_t) {
-    __shared__ WaveLds lds;
+    __shared__ WaveLds<SmallQueues> lds;
     const int lane = threadIdx.x;
     const int i = blockIdx.x * kBlock + lane;
     const bool valid = i < n_rays;
@@ -719,10 +810,11 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     if (rows <= 0 || args.width <= 0) return hipSuccess;
     const int blocks_y = (rows + 7) / 8;
     const unsigned grid = static_cast<unsigned>(args.blocks_x) * static_cast<unsigned>(blocks_y);
-    if (args.sky)
-        hipLaunchKernelGGL(integrate_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, args);
-    else
-        hipLaunchKernelGGL(integrate_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, args);
+    const bool big = args.n_tri > kBigSceneTriangles;
+    if (args.sky && big) hipLaunchKernelGGL((integrate_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+    else if (args.sky) hipLaunchKernelGGL((integrate_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, args);
+    else if (big) hipLaunchKernelGGL((integrate_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+    else hipLaunchKernelGGL((integrate_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -327,14 +327,15 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         const double reff = sphere_of(i, 1, tmp);
         large[i] = !(reff < 0.12 * r_max);
     }
-    // ---- clusters: runs of up to 256 consecutive triangles of one class
+    // ---- clusters: maximal runs of consecutive triangles of one class
     const SphereRec never = {{0, 0, 0}, -1.0e30f};
     int i = 0;
     while (i < T) {
         const bool lg = large[i];
         int n = 1;
-        while (i + n < T && n < kChunk * kClusterWords && large[i + n] == lg) ++n;
+        while (i + n < T && large[i + n] == lg) ++n;
         ClusterDesc cd;
+        std::memset(&cd, 0, sizeof cd);
         SphereRec cs;
         sphere_of(i, n, cs);
         cd.c[0] = cs.c[0]; cd.c[1] = cs.c[1]; cd.c[2] = cs.c[2]; cd.r2 = cs.r2;
@@ -344,18 +345,21 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         const int n_words = (n + kChunk - 1) / kChunk;
         if (!lg) {
             cd.data_off = static_cast<uint32_t>(out.spheres.size());
-            for (int w = 0; w < n_words; ++w) {
-                const int wf = i + w * kChunk, wn = std::min(kChunk, i + n - wf);
-                for (int o = 0; o < kChunk / kOctet; ++o) {
+            long long span = 1;   // triangles per node of the current level
+            for (int level = 0;; ++level, span *= kFan) {
+                const long long count = (n + span - 1) / span;
+                if (level > 0) cd.level_off[level - 1] = static_cast<uint32_t>(out.spheres.size() - cd.data_off);
+                for (long long j = 0; j < (count + kFan - 1) / kFan * kFan; ++j) {
                     SphereRec sr = never;
-                    const int f = wf + o * kOctet, c = std::min(kOctet, wf + wn - f);
-                    if (c > 0) sphere_of(f, c, sr);
+                    if (j < count) {
+                        const long long f = j * span;
+                        sphere_of(i + static_cast<int>(f), static_cast<int>(std::min<long long>(span, n - f)), sr);
+                    }
                     out.spheres.push_back(sr);
                 }
-                for (int k = 0; k < kChunk; ++k) {
-                    SphereRec sr = never;
-                    if (k < wn) sphere_of(wf + k, 1, sr);
-                    out.spheres.push_back(sr);
+                if (count <= kFan || level == kMaxLevels - 1) {
+                    cd.n_levels = static_cast<uint32_t>(level + 1);
+                    break;
                 }
             }
         } else {

@@ -49,23 +49,26 @@ struct MatRec {
     int32_t n_lobes, kind0, kind1, pad;   // kind: 0 emissive, 1 glossy, 2 diffuse
 };
 
-static const int kChunk = 32;   // triangles per candidate-mask word
-static const int kOctet = 8;    // triangles per sub-group of a word (its own bounding sphere)
-static const int kClusterWords = 8;   // words per cluster (256 triangles)
+static const int kChunk = 32;    // large class: triangles per candidate-mask word
+static const int kFan = 8;       // small class: children per node of the sphere tree
+static const int kMaxLevels = 8; // small class: tree levels per cluster (8^8 triangles)
 
 // Bounding sphere used by the hierarchical cull: a ray is kept for the node iff its distance to `c` is <= sqrt(r2).
 // r2 already contains every slack that makes the test conservative (see DESIGN.md "Culling").
 struct SphereRec {
     float c[3], r2;
 };
-// A cluster = up to 256 consecutive triangles of one class, cut into words of 32 (one candidate-mask word each)
-// and, for small triangles, octets of 8.
-//   kind 0 (small triangles): data_off indexes SphereRec; word w of the cluster owns 36 records from
-//                             data_off + 36 w: its 4 octet spheres, then its 32 triangle spheres
-//   kind 1 (large triangles): data_off indexes CullRec; word w owns 32 barycentric cull records from data_off + 32 w
+// A cluster = a maximal run of consecutive triangles (file order) of one class.
+//   kind 0 (small triangles): an implicit 8-ary tree of bounding spheres over the run.  Level 0 = one sphere per
+//       triangle, node j of level L covers triangles [8^L j, 8^L (j+1)); every level is padded to a multiple of 8
+//       with spheres that keep nothing.  Level L starts at SphereRec index data_off + level_off[L] (level_off[0] = 0);
+//       the top level (n_levels - 1) has at most 8 nodes.
+//   kind 1 (large triangles): data_off indexes CullRec, one barycentric cull record per triangle, padded to 32.
 struct ClusterDesc {
-    float c[3], r2;
+    float c[3], r2;                                  // bounding sphere of the whole run
     uint32_t first_tri, n_tri, kind, data_off;
+    uint32_t n_levels;
+    uint32_t level_off[kMaxLevels - 1];              // offsets of levels 1..7
 };
 
 // Margins of the barycentric cull test for one render call (depend on eps).

@@ -21,15 +21,14 @@ def _ray_sphere_keep(c, r2, o, d):
 
 
 def _layout(t):
-    """triangle index -> (cluster, word, octet sphere index, triangle sphere index) for the small class."""
+    """triangle index -> (cluster, [sphere index of its ancestor at every level, top first ... level 0 last])."""
     out = {}
     for ci in range(len(t["kind"])):
         if t["kind"][ci] != 0:
             continue
         for k in range(t["n_tri"][ci]):
-            w, j = divmod(k, 32)
-            base = t["data_off"][ci] + 36 * w
-            out[t["first_tri"][ci] + k] = (ci, base + j // 8, base + 4 + j)
+            chain = [t["data_off"][ci] + t["level_off"][ci][lv] + (k >> (3 * lv)) for lv in range(t["n_levels"][ci] - 1, -1, -1)]
+            out[t["first_tri"][ci] + k] = (ci, chain)
     return out
 
 
@@ -42,19 +41,21 @@ def test_structure_tor(tor):
     t = tor.cull_tables()
     assert list(t["first_tri"]) == [0, 256, 258, 260] and list(t["n_tri"]) == [256, 2, 2, 10]
     assert list(t["kind"]) == [0, 1, 0, 1]          # torus + light: spheres; walls: barycentric
+    assert list(t["n_levels"][[0, 2]]) == [3, 1]    # 256 -> 32 -> 4 nodes; the light's 2 triangles are their own top level
+    assert list(t["level_off"][0][:3]) == [0, 256, 288]
     assert t["n_large"] == 12
     tri, _ = tor.triangles()
     v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
     lay = _layout(t)
     assert sorted(lay) == list(range(256)) + [258, 259]
-    for i, (ci, so, st) in lay.items():
-        for sph in (t["cluster_sphere"][ci], t["spheres"][so], t["spheres"][st]):
+    for i, (ci, chain) in lay.items():
+        for sph in [t["cluster_sphere"][ci]] + [t["spheres"][k] for k in chain]:
             assert (((v[i] - sph[:3]) ** 2).sum(1) <= sph[3]).all()      # vertices inside every enclosing sphere
     # padding records can never keep a finite ray
     pads = t["spheres"][t["spheres"][:, 3] < 0]
     assert len(pads) > 0 and (pads[:, 3] <= -1e29).all()
     # the triangle spheres really are small compared with the octet and cluster spheres
-    r_tri = np.sqrt([t["spheres"][st][3] for _, _, st in lay.values()])
+    r_tri = np.sqrt([t["spheres"][chain[-1]][3] for _, chain in lay.values()])
     assert np.median(r_tri) < 1.0 and np.sqrt(t["cluster_sphere"][0][3]) < 4.5
 
 
@@ -86,9 +87,9 @@ def test_accepted_triangles_are_never_culled(tor, oracle_scene):
         if stage != 4:
             continue
         accepted += 1
-        ci, so, st = lay[int(a[i])]
+        ci, chain = lay[int(a[i])]
         o64, d64 = o32[i].astype(np.float64), d[i].astype(np.float64)
-        for sph in (t["cluster_sphere"][ci], t["spheres"][so], t["spheres"][st]):
+        for sph in [t["cluster_sphere"][ci]] + [t["spheres"][k] for k in chain]:
             assert _ray_sphere_keep(sph[:3].astype(np.float64), float(sph[3]), o64, d64)
     assert accepted > 0.5 * n
 
@@ -106,7 +107,7 @@ def test_degenerate_and_tiny_triangles_are_always_kept(tmp_path):
     assert np.isnan(t["bary"][0, 4:]).all() and np.isnan(t["bary"][1, 4:]).all()
     assert np.isfinite(t["bary"][0, :4]).any() or True   # the plane itself is whatever the reference computed
     assert np.isinf(t["cluster_sphere"][0][3])
-    assert sorted(lay) == [2] and np.isfinite(t["spheres"][lay[2][2]][3])
+    assert sorted(lay) == [2] and np.isfinite(t["spheres"][lay[2][1][-1]][3])
 
 
 def test_tables_depend_on_eps(tor):
