@@ -160,12 +160,13 @@ def main():
         kms = kernel_ms_rank0 / k
         achieved = seg * n_tri * FLOP_PER_TEST / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         algo_bytes = npx * 28 * 2 + n_tri * 112          # accumulators read + written once per launch, scene tables once
-        traffic = None
+        traffic = valu_util = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")   # written by tools/summarize_pmc.py from rocprofv3 --pmc passes
         if world == 1 and os.path.exists(pmc):
             j = json.load(open(pmc))
             if j.get("spp") == args.spp and j.get("width") == W and j.get("height") == H:
                 traffic = j.get("hbm_bytes_per_launch")
+                valu_util = j.get("valu_issue_utilisation")
         out = {
             "metric": "Msamples/sec (WxHxspp/wall) on Tor.obj 1080p",
             "value": samples_per_step * k / elapsed / 1e6,
@@ -178,9 +179,12 @@ def main():
                                    f"{world} row band(s) of {rows} rows" + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
                        "width": W, "height": H, "spp": args.spp, "max_ray_reflections": MRR, "triangles": n_tri,
                        "parallelism": f"rowband{world}"},
+            # achieved = the REFERENCE's work (segments x triangles x 31.5 flop) per second of kernel time; the kernel culls
+            # most ray-triangle pairs, so this can exceed the ALU peak -- valu_issue_utilisation_pmc is the hardware view
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "pt::integrate_kernel", "kernel_ms": kms, "segments_per_launch": seg,
+                         "kernel": "pt::integrate_kernel<false,false>", "kernel_ms": kms,
+                         "valu_issue_utilisation_pmc": valu_util, "segments_per_launch": seg,
                          "flop_per_test": FLOP_PER_TEST,
                          "hbm": {"algorithmic_bytes": algo_bytes, "achieved": algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
