@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of the frame (BASELINE configs: 64 / 256 / 1024)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget; 0 skips it")
     ap.add_argument("--write-bmp", default="", help="resolve rank 0's gathered frame and write it here")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all render on device 0 and gather over gloo (host copies): exercises the multi-rank "
+                         "code path on a one-GPU box; the number it prints is NOT a scaling result")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,11 +102,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU with torch.distributed.run")
     if not torch.cuda.is_available() or pt.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the integrator has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     W, H = bands.frame_for(world)
     r0, r1 = bands.band_rows(H, world, rank)
@@ -123,8 +131,8 @@ def main():
     def step(timed):
         band.zero_()
         st = scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=True)
-        if world > 1:
-            gathered[0] = bands.gather_bands(band, W, H, dist, rank, world)   # the frame's one collective (RCCL)
+        if world > 1:   # the frame's one collective (RCCL; gloo on host copies when rehearsing)
+            gathered[0] = bands.gather_bands(band.cpu() if args.rehearse_on_one_gpu else band, W, H, dist, rank, world)
         return st
 
     def fence():
@@ -140,11 +148,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         agg = torch.tensor([sum(s["kernel_ms"] for s in stats), float(sum(s["segments"] for s in stats)),
-                            float(sum(s["samples_traced"] for s in stats))], dtype=torch.float64, device=dev)
+                            float(sum(s["samples_traced"] for s in stats))], dtype=torch.float64, device=rdev)
         kmax = agg[:1].clone()
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)

@@ -108,3 +108,20 @@ def test_portable_sincos_tracks_libm():
         assert diff.mean() < 0.03
         ulp = np.spacing(np.maximum(np.abs(lm[diff]), np.abs(pt[diff])))
         assert np.all(np.abs(lm[diff] - pt[diff]) <= ulp)
+
+
+def test_rng_policies_agree_statistically(oracle_scene):
+    """T7: the counter RNG (Philox + portable trig) and the reference's sequential streams estimate the same image.
+    Only ~1 % of the samples reach the emitter, so the comparison is on frame totals with Poisson error bars."""
+    W, H, spp, mrr = 96, 96, 24, 8
+    a = O.render(oracle_scene, W, H, spp, mrr, rng=O.RNG_SEQUENTIAL, trig=O.TRIG_LIBM)
+    b = O.render(oracle_scene, W, H, spp, mrr, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, seed=7)
+    ca, cb = a[3]["contributing"], b[3]["contributing"]
+    assert ca > 1500 and cb > 1500
+    assert abs(ca - cb) < 5 * np.sqrt(ca + cb)                       # contributing-sample counts agree within 5 sigma
+    assert abs(a[3]["segments"] - b[3]["segments"]) < 0.01 * a[3]["segments"]
+    ma, mb = a[0].sum(0) / ca, b[0].sum(0) / cb                      # mean contribution per contributing sample, per channel
+    assert np.all(np.abs(ma - mb) < 0.08 * np.maximum(ma, mb))
+    # the directly visible light source is noise-free in both: identical counts there
+    lit_a, lit_b = a[2] == spp, b[2] == spp
+    assert lit_a.sum() > 20 and (lit_a == lit_b).mean() > 0.999
