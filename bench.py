@@ -183,7 +183,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / k * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (models/Tor.obj, 270 triangles, seed 42, counter RNG)",
+            "dtype": "f32",
+            "data": "synthetic (models/Tor.obj, 270 triangles, seed 42, counter RNG)" +
+                    (" -- REHEARSAL: all ranks on one GPU, gloo gather; not a scaling measurement" if args.rehearse_on_one_gpu else ""),
             "config": {"workload": f"Tor.obj {W}x{H} x {args.spp} spp, -MRR {MRR}, -ERR -1 (adaptive off), -EPS 1e-4; "
                                    f"{world} row band(s) of {rows} rows" + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
                        "width": W, "height": H, "spp": args.spp, "max_ray_reflections": MRR, "triangles": n_tri,
