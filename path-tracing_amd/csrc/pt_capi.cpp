@@ -108,6 +108,10 @@ int ensure_cull(pt_scene *s, float eps) {
 }
 
 int finish_scene(pt_scene *s, int device, pt_scene **out) {
+    if (s->host.n_tri() >= (1 << 24)) {   // work items carry the triangle index in 24 bits
+        delete s;
+        return fail(PT_ERR_INVALID_ARGUMENT, "more than 16 777 215 triangles");
+    }
     for (int m : s->host.tri_mat)
         if (m < 0 || m >= s->host.n_mat()) {
             delete s;

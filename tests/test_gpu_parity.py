@@ -166,3 +166,23 @@ def test_many_candidates_per_ray(tmp_path):
     o = O.Scene.load(d, "s.obj")
     st, rst = _compare(g, o, 40, 32, 8, 8)
     assert st["exact_tests"] > 20 * st["segments"]      # really many candidates per ray
+
+
+def test_tiny_and_empty_scenes(tmp_path):
+    d = str(tmp_path) + "/"
+    open(d + "m.mtl", "w").write("newmtl 0\nKe 1 1 1\nKd 0.5 0.25 1\nnewmtl 1\nNs 0\nKd 0.8 0.8 0.8\n")
+    # no triangle at all: every ray misses
+    open(d + "empty.obj", "w").write("mtllib m.mtl\nv 0 0 0\n")
+    g = pt.Scene.load_obj(d, "empty.obj", device=0)
+    s, s2, c, st = g.render_host(24, 16, 3, 8)
+    assert st["segments"] == st["misses"] == 24 * 16 * 3 and not c.any()
+    i, t = g.trace_rays(np.zeros((5, 3), np.float32), np.tile(np.array([0, 0, 1], np.float32), (5, 1)))
+    assert (i == -1).all() and np.isinf(t).all()
+    # one emissive triangle in front of the camera; one diffuse triangle behind it
+    open(d + "one.obj", "w").write("mtllib m.mtl\nv -3 -3 0\nv 3 -3 0\nv 0 4 0\nusemtl 0\nf 1 3 2\n")
+    open(d + "two.obj", "w").write("mtllib m.mtl\nv -3 -3 0\nv 3 -3 0\nv 0 4 0\nv -9 -9 5\nv 9 -9 5\nv 0 9 5\nusemtl 0\nf 1 3 2\nusemtl 1\nf 4 6 5\n")
+    for name in ("one.obj", "two.obj"):
+        g = pt.Scene.load_obj(d, name, device=0)
+        o = O.Scene.load(d, name)
+        st, rst = _compare(g, o, 40, 40, 5, 8)
+        assert st["contributing"] > 0
