@@ -126,6 +126,17 @@ int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, co
 int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count,
                float gamma, uint8_t *bgr, float *dispersion);
 
+/* The same in three steps, for the optional post filters (-GAUSS / -MEDIAN, main.cpp:187-192):
+ *   pt_resolve_float     main.cpp:162-185: statistics + the tonemapped FLOAT image (rgb: height*width*3, r,g,b order;
+ *                        pixels without samples keep their raw sums, as color_map does)
+ *   pt_post_filter_host  GaussBlur (main.cpp:11-33) if gauss != 0, then MedianFilter (main.cpp:49-80) if median != 0,
+ *                        on HIP device `device`, in place on the host image; median <= 11
+ *   pt_quantize          main.cpp:193-201: float -> uint8 truncation, only for pixels with samples */
+int pt_resolve_float(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count,
+                     float gamma, float *rgb, float *dispersion);
+int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median);
+int pt_quantize(int32_t width, int32_t height, const float *rgb, const int32_t *count, uint8_t *bgr);
+
 /* bitmap_image::save_image (bitmap_image.hpp:431-478): 54-byte header, bottom-up rows padded to 4 bytes. */
 int pt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t *bgr);
 

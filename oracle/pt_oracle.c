@@ -820,6 +820,72 @@ void orc_resolve(int W, int H, const float *sum, const float *sum2, const int *c
     disp[0] = max_d; disp[1] = min_d; disp[2] = avg_d;
 }
 
+/* main.cpp:162-185 without the byte conversion: the tonemapped float image the post filters work on.
+ * rgb: H*W*3 floats, row-major; pixels without samples keep their raw sums (zero), as color_map does. */
+void orc_resolve_float(int W, int H, const float *sum, const float *sum2, const int *count, float gamma, float *rgb, float *disp) {
+    float max_d = 0, min_d = INFINITY, avg_d = 0;
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        size_t p = (size_t)y * W + x;
+        for (int k = 0; k < 3; ++k) rgb[3 * p + k] = sum[3 * p + k];
+        if (!count[p]) { avg_d += 1; continue; }
+        const float n = (float)count[p];
+        float D[3];
+        for (int k = 0; k < 3; ++k) {
+            float m = sum[3 * p + k] / n;
+            D[k] = sum2[3 * p + k] / n - m * m;
+            rgb[3 * p + k] = powf(sum[3 * p + k] / n, gamma) * 255.0f;
+        }
+        const float d = D[0] + D[1] + D[2];
+        if (d > max_d) max_d = d;
+        if (d < min_d) min_d = d;
+        avg_d += d;
+    }
+    avg_d /= W * H;
+    if (disp) { disp[0] = max_d; disp[1] = min_d; disp[2] = avg_d; }
+}
+/* GaussBlur, main.cpp:11-33 (clamp-to-edge taps, weights exp(-d2/(2r^2))/(2 pi r^2) in float, glm::round). */
+void orc_gauss_blur(int W, int H, const float *in, float r, float *out) {
+    const float pi = 3.141593f;
+    const int rs = (int)ceil(r * 2.57);
+    for (int i = 0; i < H; ++i) for (int j = 0; j < W; ++j) {
+        float val[3] = { 0, 0, 0 }, wsum = 0;
+        for (int iy = i - rs; iy <= i + rs; ++iy) for (int ix = j - rs; ix <= j + rs; ++ix) {
+            const int x = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix), y = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+            const int dsq = (ix - j) * (ix - j) + (iy - i) * (iy - i);
+            const float wght = expf(-dsq / (2 * r * r)) / (pi * 2 * r * r);
+            for (int k = 0; k < 3; ++k) val[k] += in[3 * ((size_t)y * W + x) + k] * wght;
+            wsum += wght;
+        }
+        for (int k = 0; k < 3; ++k) out[3 * ((size_t)i * W + j) + k] = roundf(val[k] / wsum);
+    }
+}
+static int cmp_float(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+/* MedianFilter, main.cpp:49-80: element window_size*window_size/2 of the sorted (2w+1)^2 window (sic). */
+void orc_median_filter(int W, int H, const float *in, int ws, float *out) {
+    const int n = (2 * ws + 1) * (2 * ws + 1);
+    float *win = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) for (int k = 0; k < 3; ++k) {
+        int m = 0;
+        for (int wx = -ws; wx < ws + 1; ++wx) for (int wy = -ws; wy < ws + 1; ++wy) {
+            const int i = wx + x > W - 1 ? W - 1 : (wx + x < 0 ? 0 : wx + x), j = wy + y > H - 1 ? H - 1 : (wy + y < 0 ? 0 : wy + y);
+            win[m++] = in[3 * ((size_t)j * W + i) + k];
+        }
+        qsort(win, (size_t)n, sizeof(float), cmp_float);
+        out[3 * ((size_t)y * W + x) + k] = win[ws * ws / 2];
+    }
+    free(win);
+}
+/* main.cpp:193-201 + set_pixel's float -> uchar conversion: only pixels with samples are written. */
+void orc_quantize(int W, int H, const float *rgb, const int *count, unsigned char *bgr) {
+    memset(bgr, 0, (size_t)W * H * 3);
+    for (size_t p = 0; p < (size_t)W * H; ++p) {
+        if (!count[p]) continue;
+        bgr[3 * p + 0] = (unsigned char)(int)rgb[3 * p + 2];
+        bgr[3 * p + 1] = (unsigned char)(int)rgb[3 * p + 1];
+        bgr[3 * p + 2] = (unsigned char)(int)rgb[3 * p + 0];
+    }
+}
+
 /* bitmap_image::save_image, bitmap_image.hpp:431-478 (headers :1302-1358). Returns bytes written, 0 on failure. */
 size_t orc_write_bmp(const char *path, int W, int H, const unsigned char *bgr) {
     FILE *f = fopen(path, "wb");

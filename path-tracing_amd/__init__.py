@@ -24,7 +24,8 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT
 # every symbol include/pt_hip.h declares
 ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
                "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_trace_rays_host",
-               "pt_scene_cull_tables", "pt_scene_set_skybox_bmp", "pt_resolve",
+               "pt_scene_cull_tables", "pt_scene_set_skybox_bmp", "pt_resolve", "pt_resolve_float",
+               "pt_post_filter_host", "pt_quantize",
                "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
 
 
@@ -81,6 +82,9 @@ def lib():
         L.pt_scene_cull_tables.argtypes = [vp, C.c_float, ip, fp, fp, fp, fp]
         L.pt_scene_set_skybox_bmp.argtypes = [vp, C.c_char_p]
         L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
+        L.pt_resolve_float.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, fp, fp]
+        L.pt_post_filter_host.argtypes = [C.c_int, C.c_int32, C.c_int32, fp, C.c_int32, C.c_int32]
+        L.pt_quantize.argtypes = [C.c_int32, C.c_int32, fp, ip, C.POINTER(C.c_uint8)]
         L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.pt_last_error.restype = C.c_char_p
         _lib = L
@@ -217,6 +221,33 @@ def resolve(width, height, s, s2, c, gamma=None):
     _check(lib().pt_resolve(width, height, _fp(s), _fp(s2), _ip(c), C.c_float(gamma),
                             bgr.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(disp)))
     return bgr, disp
+
+
+def resolve_float(width, height, s, s2, c, gamma=None):
+    """main.cpp:162-185: (rgb float32 [H,W,3] tonemapped image, dispersion float32[3])."""
+    if gamma is None:
+        gamma = np.float32(1) / np.float32(2.2)
+    rgb = np.zeros((height, width, 3), np.float32)
+    disp = np.zeros(3, np.float32)
+    _check(lib().pt_resolve_float(width, height, _fp(np.ascontiguousarray(s, np.float32)), _fp(np.ascontiguousarray(s2, np.float32)),
+                                  _ip(np.ascontiguousarray(c, np.int32)), C.c_float(gamma), _fp(rgb), _fp(disp)))
+    return rgb, disp
+
+
+def post_filter(rgb, gauss=0, median=0, device=0):
+    """-GAUSS / -MEDIAN (main.cpp:187-192) on the GPU; returns the filtered float image."""
+    out = np.ascontiguousarray(rgb, np.float32).copy()
+    h, w, _ = out.shape
+    _check(lib().pt_post_filter_host(device, w, h, _fp(out), gauss, median))
+    return out
+
+
+def quantize(rgb, c):
+    h, w, _ = rgb.shape
+    bgr = np.zeros((h, w, 3), np.uint8)
+    _check(lib().pt_quantize(w, h, _fp(np.ascontiguousarray(rgb, np.float32)), _ip(np.ascontiguousarray(c, np.int32)),
+                             bgr.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return bgr
 
 
 def write_bmp(path, bgr):

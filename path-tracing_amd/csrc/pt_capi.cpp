@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "pt_filters.hpp"
 #include "pt_kernels.hpp"
 #include "pt_scene.hpp"
 
@@ -474,6 +476,97 @@ int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum
         dispersion[0] = max_d;
         dispersion[1] = min_d;
         dispersion[2] = avg_d;
+    }
+    return PT_OK;
+}
+
+int pt_resolve_float(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
+                     float *rgb, float *dispersion) {
+    if (width <= 0 || height <= 0 || !sum || !sum2 || !count || !rgb)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
+    float max_d = 0.0f, min_d = INFINITY, avg_d = 0.0f;
+    for (int y = 0; y < height; ++y) {
+        for (int x = 0; x < width; ++x) {
+            const size_t p = static_cast<size_t>(y) * width + x;
+            for (int k = 0; k < 3; ++k) rgb[3 * p + k] = sum[3 * p + k];   // color_map keeps its raw sums where nothing was counted
+            if (!count[p]) {
+                avg_d += 1;
+                continue;
+            }
+            const float n = static_cast<float>(count[p]);
+            float dd[3];
+            for (int k = 0; k < 3; ++k) {
+                const float mean = sum[3 * p + k] / n;
+                dd[k] = sum2[3 * p + k] / n - mean * mean;
+                rgb[3 * p + k] = std::pow(sum[3 * p + k] / n, gamma) * 255.0f;
+            }
+            const float d = dd[0] + dd[1] + dd[2];
+            if (d > max_d) max_d = d;
+            if (d < min_d) min_d = d;
+            avg_d += d;
+        }
+    }
+    avg_d /= width * height;
+    if (dispersion) {
+        dispersion[0] = max_d;
+        dispersion[1] = min_d;
+        dispersion[2] = avg_d;
+    }
+    return PT_OK;
+}
+
+int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median) {
+    if (width <= 0 || height <= 0 || !rgb) return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
+    if (gauss < 0 || median < 0) return fail(PT_ERR_INVALID_ARGUMENT, "negative filter size");
+    if (median * median / 2 > pt::kMedianMaxRank) return fail(PT_ERR_INVALID_ARGUMENT, "-MEDIAN window larger than 11 is not supported");
+    if (!gauss && !median) return PT_OK;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev)
+        return fail(PT_ERR_NO_DEVICE, "no usable HIP device for the post filters (there is no CPU fallback)");
+    PT_HIP_TRY(hipSetDevice(device));
+    const size_t bytes = static_cast<size_t>(width) * height * 3 * sizeof(float);
+    float *d_a = nullptr, *d_b = nullptr, *d_w = nullptr;
+    int result = PT_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_a), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_b), bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_a, rgb, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && gauss) {   // main.cpp:187-189
+        const float r = static_cast<float>(gauss), pi = 3.141593f;
+        const int rs = static_cast<int>(std::ceil(r * 2.57));
+        const int side = 2 * rs + 1;
+        std::vector<float> w(static_cast<size_t>(side) * side);
+        for (int dy = -rs; dy <= rs; ++dy)
+            for (int dx = -rs; dx <= rs; ++dx) {
+                const int dsq = dx * dx + dy * dy;
+                w[static_cast<size_t>(dy + rs) * side + (dx + rs)] = std::exp(-dsq / (2 * r * r)) / (pi * 2 * r * r);   // main.cpp:25
+            }
+        e = hipMalloc(reinterpret_cast<void **>(&d_w), w.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = pt::launch_gauss(d_a, d_b, d_w, width, height, rs, nullptr);
+        std::swap(d_a, d_b);
+    }
+    if (e == hipSuccess && median) {   // main.cpp:190-192
+        e = pt::launch_median(d_a, d_b, width, height, median, nullptr);
+        std::swap(d_a, d_b);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(rgb, d_a, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) result = hip_fail(e, "pt_post_filter_host");
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (d_w) (void)hipFree(d_w);
+    return result;
+}
+
+int pt_quantize(int32_t width, int32_t height, const float *rgb, const int32_t *count, uint8_t *bgr) {
+    if (width <= 0 || height <= 0 || !rgb || !count || !bgr) return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
+    const size_t n = static_cast<size_t>(width) * height;
+    std::memset(bgr, 0, n * 3);
+    for (size_t p = 0; p < n; ++p) {   // main.cpp:193-201: only pixels with samples are written
+        if (!count[p]) continue;
+        bgr[3 * p + 0] = static_cast<uint8_t>(static_cast<int>(rgb[3 * p + 2]));
+        bgr[3 * p + 1] = static_cast<uint8_t>(static_cast<int>(rgb[3 * p + 1]));
+        bgr[3 * p + 2] = static_cast<uint8_t>(static_cast<int>(rgb[3 * p + 0]));
     }
     return PT_OK;
 }

@@ -198,30 +198,6 @@ __device__ __forceinline__ float area_of(float ax, float ay, float az, float bx,
     return __builtin_sqrtf(cx * cx + cy * cy + cz * cz);
 }
 
-__device__ __forceinline__ bool exact_intersect(const ExactRec *__restrict__ rec, const Ray &q, float eps, float &best) {
-    const float4 r0 = reinterpret_cast<const float4 *>(rec)[0];   // plane
-    const float4 r1 = reinterpret_cast<const float4 *>(rec)[1];   // v0, square
-    const float4 r2 = reinterpret_cast<const float4 *>(rec)[2];   // v1, material
-    const float4 r3 = reinterpret_cast<const float4 *>(rec)[3];   // v2
-    const float signed_dist = q.dx * r0.x + q.dy * r0.y + q.dz * r0.z;
-    const float nd = -(q.ox * r0.x + q.oy * r0.y + q.oz * r0.z + r0.w) / signed_dist;
-    const bool stage_a = !(nd >= best || nd < eps);
-    const float px = q.ox + q.dx * nd, py = q.oy + q.dy * nd, pz = q.oz + q.dz * nd;
-    const float f0x = px - r1.x, f0y = py - r1.y, f0z = pz - r1.z;
-    const float f1x = px - r2.x, f1y = py - r2.y, f1z = pz - r2.z;
-    const float f2x = px - r3.x, f2y = py - r3.y, f2z = pz - r3.z;
-    const float sq = r1.w;
-    const float s1 = area_of(f0x, f0y, f0z, f1x, f1y, f1z);
-    const bool stage_b = !(s1 > sq + eps);
-    const float s2 = area_of(f0x, f0y, f0z, f2x, f2y, f2z);
-    const bool stage_c = !(s1 + s2 > sq + eps);
-    const float s3 = area_of(f2x, f2y, f2z, f1x, f1y, f1z);
-    const bool stage_d = !(__builtin_fabsf(sq - s1 - s2 - s3) > eps);
-    const bool hit = stage_a && stage_b && stage_c && stage_d;
-    if (hit) best = nd;
-    return hit;
-}
-
 // Stages B-D of Triangle::Intersect for one (ray, triangle) pair, without the running `distance`:
 // returns new_distance if the point passes the area tests, -inf otherwise (then stage A rejects it: -inf < eps).
 __device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, const Ray &q, float eps) {

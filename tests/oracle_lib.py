@@ -56,6 +56,10 @@ def lib():
         L.orc_scene_get_materials.argtypes = [vp, fp]
         L.orc_render.argtypes = [vp, C.POINTER(Params), fp, fp, ip, C.POINTER(Stats)]
         L.orc_resolve.argtypes = [C.c_int, C.c_int, fp, fp, ip, C.c_float, C.POINTER(C.c_ubyte), fp]
+        L.orc_resolve_float.argtypes = [C.c_int, C.c_int, fp, fp, ip, C.c_float, fp, fp]
+        L.orc_gauss_blur.argtypes = [C.c_int, C.c_int, fp, C.c_float, fp]
+        L.orc_median_filter.argtypes = [C.c_int, C.c_int, fp, C.c_int, fp]
+        L.orc_quantize.argtypes = [C.c_int, C.c_int, fp, ip, C.POINTER(C.c_ubyte)]
         L.orc_write_bmp.restype = C.c_size_t
         L.orc_write_bmp.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
         L.orc_closest_hit.argtypes = [vp, fp, fp, C.c_float, fp]
@@ -173,6 +177,35 @@ def resolve(width, height, s, s2, c, gamma=np.float32(1 / np.float32(2.2))):
     lib().orc_resolve(width, height, _fp(s), _fp(s2), _ip(c), C.c_float(gamma),
                       bgr.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(disp))
     return bgr, disp
+
+
+def resolve_float(width, height, s, s2, c, gamma=np.float32(1 / np.float32(2.2))):
+    rgb = np.zeros((height, width, 3), np.float32)
+    disp = np.zeros(3, np.float32)
+    lib().orc_resolve_float(width, height, _fp(s), _fp(s2), _ip(c), C.c_float(gamma), _fp(rgb), _fp(disp))
+    return rgb, disp
+
+
+def gauss_blur(rgb, r):
+    h, w, _ = rgb.shape
+    out = np.zeros_like(rgb)
+    lib().orc_gauss_blur(w, h, _fp(np.ascontiguousarray(rgb, np.float32)), C.c_float(r), _fp(out))
+    return out
+
+
+def median_filter(rgb, ws):
+    h, w, _ = rgb.shape
+    out = np.zeros_like(rgb)
+    lib().orc_median_filter(w, h, _fp(np.ascontiguousarray(rgb, np.float32)), ws, _fp(out))
+    return out
+
+
+def quantize(rgb, c):
+    h, w, _ = rgb.shape
+    bgr = np.zeros((h, w, 3), np.uint8)
+    lib().orc_quantize(w, h, _fp(np.ascontiguousarray(rgb, np.float32)), _ip(np.ascontiguousarray(c, np.int32)),
+                       bgr.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return bgr
 
 
 def write_bmp(path, bgr):

@@ -7,7 +7,6 @@
 //
 // Extra flags (not in the reference): -OUT <file> writes only that file instead of the two reference outputs,
 // -DEVICE <n> selects the HIP device, -QUIET 1 drops the per-pass lines.
-// Not available in this build (SURVEY.md 8(f) "next" row): -GAUSS, -MEDIAN with a non-default value.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -75,11 +74,6 @@ int main(int argc, char **argv) {
     const long long start_time = now_ms();
     Options o;
     parse(argc, argv, o);
-    if (o.gauss || o.median) {
-        std::cerr << "pt_render: -GAUSS / -MEDIAN are not part of this build (the post filters are the next row of the "
-                     "hot-path plan)" << std::endl;
-        return 2;
-    }
     if (o.width <= 0 || o.height <= 0) {
         std::cerr << "pt_render: --W and --H must be positive" << std::endl;
         return 2;
@@ -127,7 +121,14 @@ int main(int argc, char **argv) {
         rays_count = slice_end;
     }
 
-    pt_resolve(o.width, o.height, sum.data(), sum2.data(), count.data(), o.gamma_correction, bgr.data(), disp);
+    if (o.gauss || o.median) {   // main.cpp:187-201: filters act on the tonemapped float image, then set_pixel
+        std::vector<float> rgb(3 * px);
+        pt_resolve_float(o.width, o.height, sum.data(), sum2.data(), count.data(), o.gamma_correction, rgb.data(), disp);
+        if (pt_post_filter_host(o.device, o.width, o.height, rgb.data(), o.gauss, o.median) != PT_OK) return die("pt_render");
+        pt_quantize(o.width, o.height, rgb.data(), count.data(), bgr.data());
+    } else {
+        pt_resolve(o.width, o.height, sum.data(), sum2.data(), count.data(), o.gamma_correction, bgr.data(), disp);
+    }
     const long long end_time = now_ms();
     const std::time_t t = std::time(nullptr);
     const std::tm *now = std::localtime(&t);
