@@ -36,6 +36,8 @@ struct pt_scene {
     pt::ExactRec *d_exact = nullptr;
     pt::MatRec *d_mats = nullptr;
     unsigned long long *d_stats = nullptr;
+    uint32_t *d_sched = nullptr;   // ticket + per-tile chunk counters of the integrator's scheduler
+    size_t sched_words = 0;
     std::vector<uint8_t> sky;   // skybox texels (B,G,R; top-down rows; no padding), empty = none
     int sky_w = 0, sky_h = 0;
     uint8_t *d_sky = nullptr;
@@ -275,6 +277,7 @@ void pt_scene_destroy(pt_scene *s) {
         if (s->d_mats) (void)hipFree(s->d_mats);
         if (s->d_stats) (void)hipFree(s->d_stats);
         if (s->d_sky) (void)hipFree(s->d_sky);
+        if (s->d_sched) (void)hipFree(s->d_sched);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
     }
@@ -311,6 +314,29 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     a.eps = p->eps; a.error = p->error; a.seed = p->seed;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
     a.blocks_x = (p->width + 7) / 8;
+    // Scheduler: cut the pass range into chunks so that the launch has enough work items to balance its tail
+    // (about 24 per wave slot of the chip), but keep chunks of at least 4 passes.
+    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + 7) / 8);
+    if (n_tiles == 0) return PT_OK;
+    const uint32_t slots = 256u * 4u * 6u;
+    uint32_t n_chunks = (24u * slots + n_tiles - 1u) / n_tiles;
+    n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
+    const int32_t chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
+    n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
+    if (static_cast<unsigned long long>(n_tiles) * n_chunks > 0x7fffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "too many work items");
+    if (scene->sched_words < 1 + static_cast<size_t>(n_tiles)) {
+        PT_HIP_TRY(hipStreamSynchronize(stream));
+        if (scene->d_sched) (void)hipFree(scene->d_sched);
+        scene->d_sched = nullptr;
+        scene->sched_words = 0;
+        PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scene->d_sched), (1 + static_cast<size_t>(n_tiles)) * sizeof(uint32_t)));
+        scene->sched_words = 1 + static_cast<size_t>(n_tiles);
+    }
+    PT_HIP_TRY(hipMemsetAsync(scene->d_sched, 0, (1 + static_cast<size_t>(n_tiles)) * sizeof(uint32_t), stream));
+    a.sched = scene->d_sched;
+    a.n_tiles = n_tiles;
+    a.n_chunks = n_chunks;
+    a.chunk_passes = chunk_passes;
     if (stats) {
         PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
         PT_HIP_TRY(hipEventRecord(scene->ev0, stream));

@@ -536,8 +536,28 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
-    const int x = (blockIdx.x % a.blocks_x) * 8 + (lane & 7);
-    const int y = a.row_begin + (blockIdx.x / a.blocks_x) * 8 + (lane >> 3);
+    // Work item = (pixel tile, chunk of passes), claimed from a ticket counter in chunk-major order: all tiles' first
+    // chunk, then all tiles' second chunk, ...  Cutting the pass range into chunks gives the tail of the launch small
+    // items to balance with (at 1080p x 64 spp one tile per wave left the last of 5.3 rounds a quarter full).
+    // A chunk may only start once the tile's previous chunk has published its accumulators; because tickets are
+    // taken in execution order, that chunk was claimed earlier by a wave that is running or done, so the wait below
+    // cannot deadlock, and with thousands of tiles between two chunks of one tile it practically never waits.
+    uint32_t item = 0;
+    if (lane == 0) item = atomicAdd(&a.sched[0], 1u);
+    item = __builtin_amdgcn_readfirstlane(item);
+    const uint32_t tile = item % a.n_tiles, chunk = item / a.n_tiles;
+    const int pass_first = a.pass_begin + static_cast<int>(chunk) * a.chunk_passes;
+    const int pass_last = min(a.pass_begin + a.pass_count, pass_first + a.chunk_passes);
+    if (chunk > 0) {
+        if (lane == 0) {
+            while (__hip_atomic_load(&a.sched[1 + tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one poll, one agent-scope acquire, then plain loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int x = static_cast<int>(tile % a.blocks_x) * 8 + (lane & 7);
+    const int y = a.row_begin + static_cast<int>(tile / a.blocks_x) * 8 + (lane >> 3);
     const bool in_image = x < a.width && y < a.row_end;
     const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
     const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
@@ -576,7 +596,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
     const int mrr = a.mrr;
     const float eps = a.eps;
 
-    for (int pass = a.pass_begin; pass < a.pass_begin + a.pass_count; ++pass) {
+    for (int pass = pass_first; pass < pass_last; ++pass) {
         // Adaptive skip, main.cpp:118-125.
         const bool skip = !in_image || (pass > 10 && (pass % 4) && lowvar);
         if (__all(skip)) continue;
@@ -733,6 +753,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         }
         a.count[pe] = __float_as_int(lds.acc[6][lane]);
     }
+    if (chunk + 1 < a.n_chunks) {   // publish the tile's accumulators to the wave that takes its next chunk
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler (guide, G16)
+        if (lane == 0) __hip_atomic_store(&a.sched[1 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (a.stats && lane == 0) {
         atomicAdd(&a.stats[0], static_cast<unsigned long long>(n_traced));
         atomicAdd(&a.stats[1], static_cast<unsigned long long>(n_segments));
@@ -784,8 +810,7 @@ hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, con
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     const int rows = args.row_end - args.row_begin;
     if (rows <= 0 || args.width <= 0) return hipSuccess;
-    const int blocks_y = (rows + 7) / 8;
-    const unsigned grid = static_cast<unsigned>(args.blocks_x) * static_cast<unsigned>(blocks_y);
+    const unsigned grid = args.n_tiles * args.n_chunks;
     const bool big = args.n_tri > kBigSceneTriangles;
     if (args.sky && big) hipLaunchKernelGGL((integrate_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, args);
     else if (args.sky) hipLaunchKernelGGL((integrate_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, args);

@@ -28,6 +28,9 @@ struct RenderArgs {
     uint32_t seed;
     float k1, k2, a_max, m0, t_guard;   // cull margins (pt_scene.hpp: CullConstants)
     int32_t blocks_x;                   // ceil(width / 8)
+    uint32_t *sched;                    // [0] ticket counter, [1 + tile] chunks of that tile already published; zeroed per launch
+    uint32_t n_tiles, n_chunks;         // work items = n_tiles * n_chunks, chunk-major
+    int32_t chunk_passes;               // passes per chunk
 };
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);
