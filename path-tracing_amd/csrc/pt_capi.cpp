@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -319,7 +320,9 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + 7) / 8);
     if (n_tiles == 0) return PT_OK;
     const uint32_t slots = 256u * 4u * 6u;
-    uint32_t n_chunks = (24u * slots + n_tiles - 1u) / n_tiles;
+    uint32_t per_slot = 24u;
+    if (const char *e = std::getenv("PT_ITEMS_PER_SLOT")) per_slot = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // tuning knob
+    uint32_t n_chunks = (per_slot * slots + n_tiles - 1u) / n_tiles;
     n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
     const int32_t chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
     n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
