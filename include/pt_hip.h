@@ -72,8 +72,8 @@ typedef struct pt_render_stats {
     uint64_t exact_tests;           /* ray-triangle pairs that needed the reference's full arithmetic */
     uint64_t misses;                /* segments that found no triangle */
     uint64_t wave_segments;         /* wave-level: segment-loop iterations summed over wavefronts */
-    uint64_t wave_octets;           /* wave-level: 8-triangle groups whose triangle spheres were tested */
-    uint64_t wave_exact_iterations; /* wave-level: iterations of the (divergent) exact-test loop */
+    uint64_t wave_node_rounds;      /* wave-level: rounds of the lane-balanced sphere-tree walk */
+    uint64_t wave_exact_iterations; /* wave-level: rounds of the lane-balanced exact tests */
     float kernel_ms;                /* HIP-event time of the integrator kernel on the launch stream; <0 if not timed */
     int32_t n_triangles;
 } pt_render_stats;

@@ -44,7 +44,7 @@ class RenderParams(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("samples_traced", C.c_uint64), ("segments", C.c_uint64), ("contributing", C.c_uint64),
                 ("exact_tests", C.c_uint64), ("misses", C.c_uint64), ("wave_segments", C.c_uint64),
-                ("wave_octets", C.c_uint64), ("wave_exact_iterations", C.c_uint64), ("kernel_ms", C.c_float),
+                ("wave_node_rounds", C.c_uint64), ("wave_exact_iterations", C.c_uint64), ("kernel_ms", C.c_float),
                 ("n_triangles", C.c_int32)]
 
     def as_dict(self):

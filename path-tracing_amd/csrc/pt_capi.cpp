@@ -26,6 +26,7 @@ struct DeviceCull {
     pt::ClusterDesc *clusters = nullptr;
     pt::SphereRec *spheres = nullptr;
     pt::CullRec *bary = nullptr;
+    pt::CullRec *bary_all = nullptr;
 };
 
 struct pt_scene {
@@ -107,6 +108,11 @@ int ensure_cull(pt_scene *s, float eps) {
     if ((rc = upload_vec(c.host.clusters, &c.clusters)) != PT_OK) return rc;
     if ((rc = upload_vec(c.host.spheres, &c.spheres)) != PT_OK) return rc;
     if ((rc = upload_vec(c.host.bary, &c.bary)) != PT_OK) return rc;
+    if (c.bary_all) {
+        (void)hipFree(c.bary_all);
+        c.bary_all = nullptr;
+    }
+    if (!c.host.bary_all.empty() && (rc = upload_vec(c.host.bary_all, &c.bary_all)) != PT_OK) return rc;
     c.eps = eps;
     c.valid = true;
     return PT_OK;
@@ -274,6 +280,7 @@ void pt_scene_destroy(pt_scene *s) {
         if (s->cull.clusters) (void)hipFree(s->cull.clusters);
         if (s->cull.spheres) (void)hipFree(s->cull.spheres);
         if (s->cull.bary) (void)hipFree(s->cull.bary);
+        if (s->cull.bary_all) (void)hipFree(s->cull.bary_all);
         if (s->d_exact) (void)hipFree(s->d_exact);
         if (s->d_mats) (void)hipFree(s->d_mats);
         if (s->d_stats) (void)hipFree(s->d_stats);
@@ -299,6 +306,10 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     a.clusters = scene->cull.clusters;
     a.spheres = scene->cull.spheres;
     a.bary = scene->cull.bary;
+    a.bary_all = scene->cull.bary_all;
+    a.a_max_all = scene->cull.host.cc_all.a_max;
+    a.m0_all = scene->cull.host.cc_all.m0;
+    a.t_guard_all = scene->cull.host.cc_all.t_guard;
     a.exact = scene->d_exact;
     a.mats = scene->d_mats;
     a.sky = scene->d_sky;
@@ -358,7 +369,7 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
         stats->exact_tests = h[3];
         stats->misses = h[4];
         stats->wave_segments = h[5];
-        stats->wave_octets = h[6];
+        stats->wave_node_rounds = h[6];
         stats->wave_exact_iterations = h[7];
         stats->kernel_ms = ms;
         stats->n_triangles = scene->host.n_tri();
@@ -387,6 +398,10 @@ int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, co
     a.clusters = scene->cull.clusters;
     a.spheres = scene->cull.spheres;
     a.bary = scene->cull.bary;
+    a.bary_all = scene->cull.bary_all;
+    a.a_max_all = scene->cull.host.cc_all.a_max;
+    a.m0_all = scene->cull.host.cc_all.m0;
+    a.t_guard_all = scene->cull.host.cc_all.t_guard;
     a.exact = scene->d_exact;
     a.mats = scene->d_mats;
     a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());

@@ -2,15 +2,16 @@
 // all passes x segments x triangles of a row band in one launch.
 //
 // Per path segment a wave does three things:
-//   1. CULL   wave-uniform walk over a three-level hierarchy of bounding spheres (cluster of 256 triangles -> octet of
-//             8 -> triangle); a node is skipped when no lane's ray comes near it.  Node records arrive through scalar
-//             loads and are used straight from SGPRs, the lanes' rays stay in VGPRs.  Large triangles (walls) get a
-//             barycentric test instead of a sphere.  Every test is CONSERVATIVE with respect to the reference's
-//             Triangle::Intersect (triangles.h:48-73): it may only say "cannot be a hit".  Survivors are recorded as
-//             one bit per triangle in per-lane mask words parked in LDS.
-//   2. EXACT  for the few survivors (about two per ray), each lane walks its own list in triangle order and runs the
-//             reference's arithmetic operation for operation (same association, no FMA contraction, IEEE divide and
-//             sqrt), so `t`, the hit decision and the closest-hit choice are bit-identical to the CPU path.
+//   1. CULL   the triangles of a cluster (a run of small triangles) hang under an 8-ary tree of bounding spheres.  The
+//             top of the tree is tested wave-uniformly (records through scalar loads, used straight from SGPRs); below
+//             it the wave keeps a LIFO of (ray, node) work items in LDS and deals them out evenly, lane l expanding the
+//             l-th item whoever's ray it is.  Large triangles (walls) get a barycentric test instead of spheres.
+//             Every test is CONSERVATIVE with respect to the reference's Triangle::Intersect (triangles.h:48-73): it
+//             may only say "cannot be a hit".  Survivors become (ray, triangle) pairs in a second LDS queue.
+//   2. EXACT  the pairs (about 1.5 per ray) are dealt out evenly as well; each runs the reference's arithmetic operation
+//             for operation (same association, no FMA contraction, IEEE divide and sqrt), and the closest hit per ray is
+//             taken with one LDS atomic-min on (distance, index), so `t`, the hit decision and the closest-hit choice
+//             are bit-identical to the CPU path.
 //   3. SHADE  Material::Process + the three lobes (material.h:36-102), Ray::Reflect (ray.h:45-50), accumulators in
 //             registers (material.h:74-77), counter-based Philox4x32-10 randoms keyed by (seed | pixel, pass, segment).
 //
@@ -28,9 +29,6 @@ namespace pt {
 
 namespace {
 
-#ifndef PT_OCTET_UNROLL
-#define PT_OCTET_UNROLL 4
-#endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 6
 #endif
@@ -38,9 +36,8 @@ constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per w
 // Capacity of the two wave-private work queues.  Small scenes (Tor.obj) keep them small so that 5 KB of LDS per wave
 // leaves room for 6+ waves per SIMD; scenes with thousands of triangles get deep queues (fuller rounds) and pay with
 // occupancy, which matters less there.
-constexpr int kBigSceneTriangles = 2048;
-struct SmallQueues { static constexpr int kNodeStack = 96, kPairQueue = 144; };
-struct BigQueues { static constexpr int kNodeStack = 832, kPairQueue = 512; };
+struct SmallQueues { static constexpr int kNodeStack = 96, kPairQueue = 144, kFiltered = 1; };
+struct BigQueues { static constexpr int kNodeStack = 832, kPairQueue = 512, kFiltered = 128; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -250,6 +247,8 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 template <class Q>
 struct WaveLds {
     static constexpr int kNodeStack = Q::kNodeStack, kPairQueue = Q::kPairQueue;
+    static constexpr bool kPrefilter = Q::kFiltered > 1;   // big scenes: thin the pairs with the barycentric test first
+    uint32_t filtered[Q::kFiltered];   // pairs that survived the pre-filter, waiting for a full exact round
     unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
     float ray[6][64];              // this segment's rays, readable by every lane
     uint32_t nodes[kNodeStack + 64];// LIFO of tree nodes to expand: lane << 26 | level << 23 | node index within its level
@@ -259,7 +258,7 @@ struct WaveLds {
     float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
 };
 struct WaveStats {
-    uint32_t n_exact = 0, w_segments = 0, w_octets = 0, w_exact_iters = 0;   // wave-uniform, live in SGPRs
+    uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0;   // wave-uniform, live in SGPRs
 #ifdef PT_PHASE_TIMERS
     // diagnostic build only: shader-clock cycles per phase (never compiled into the shipped library)
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -311,21 +310,55 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     // The reference keeps, in triangle order, every accepted triangle with new_distance < distance
     // (scene.cpp:116-120, triangles.h:51), i.e. the lexicographic minimum of (new_distance, index) over the triangles
     // that pass Triangle::Intersect with eps <= new_distance < inf: that minimum is taken with one LDS atomic per pair.
+    uint32_t n_filtered = 0;   // wave-uniform fill level of lds.filtered (big scenes)
+    auto exact_round = [&](uint32_t e, bool active, uint32_t cnt) {
+        ++st.w_exact_iters;
+        st.n_exact += cnt;
+        if (active) {
+            const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
+            Ray r;
+            r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+            r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+            const float nd = exact_inside(a.exact + tri, r, eps);   // -inf unless stages B-D pass
+            if (nd >= eps && nd < __builtin_inff())
+                atomicMin(&lds.best[src], (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | tri);
+        }
+    };
     auto drain_pairs = [&](uint32_t keep_below) {
         while (n_pairs > keep_below) {
             const uint32_t cnt = min(64u, n_pairs);
             n_pairs -= cnt;
-            ++st.w_exact_iters;
-            st.n_exact += cnt;
-            if (static_cast<uint32_t>(lane) < cnt) {
-                const uint32_t e = lds.pairs[n_pairs + lane];
-                const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
-                Ray r;
-                r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
-                r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
-                const float nd = exact_inside(a.exact + tri, r, eps);   // -inf unless stages B-D pass
-                if (nd >= eps && nd < __builtin_inff())
-                    atomicMin(&lds.best[src], (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | tri);
+            const bool active = static_cast<uint32_t>(lane) < cnt;
+            const uint32_t e = active ? lds.pairs[n_pairs + lane] : 0u;
+            if constexpr (!Lds::kPrefilter) {
+                exact_round(e, active, cnt);
+            } else {
+                // A scene with thousands of small triangles yields ~8 sphere survivors per ray; the 30-instruction
+                // barycentric test (conservative, like every cull) removes most of them before the 170-instruction exact
+                // test, and the survivors are re-packed so that exact rounds stay full.
+                bool keep = false;
+                if (active) {
+                    const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
+                    Ray r;
+                    r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                    r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                    const float4 *rp = reinterpret_cast<const float4 *>(a.bary_all + tri);
+                    const float4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
+                    CullRec rec;
+                    rec.n[0] = c0.x; rec.n[1] = c0.y; rec.n[2] = c0.z; rec.w = c0.w;
+                    rec.au[0] = c1.x; rec.au[1] = c1.y; rec.au[2] = c1.z; rec.cu = c1.w;
+                    rec.av[0] = c2.x; rec.av[1] = c2.y; rec.av[2] = c2.z; rec.cv = c2.w;
+                    keep = !cull_reject(rec, r, a.k1, a.k2, a.a_max_all, a.m0_all, a.t_guard_all);
+                }
+                const unsigned long long ball = __ballot(keep);
+                if (keep) lds.filtered[n_filtered + lanes_below(ball)] = e;
+                n_filtered += __builtin_popcountll(ball);
+                wave_sync();
+                if (n_filtered >= 64u) {
+                    n_filtered -= 64u;
+                    exact_round(lds.filtered[n_filtered + lane], true, 64u);
+                    wave_sync();
+                }
             }
             wave_sync();
         }
@@ -432,7 +465,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     }
                     wave_sync();
                 }
-                ++st.w_octets;
+                ++st.w_node_rounds;
                 const uint32_t cnt = min(64u, n_nodes);
                 uint32_t m8 = 0, src = 0, level = 1, child0 = 0;
                 if (static_cast<uint32_t>(lane) < cnt) {
@@ -518,6 +551,14 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     }
     PT_STAMP(st, 1);
     drain_pairs(0);
+    if constexpr (Lds::kPrefilter) {
+        if (n_filtered > 0) {
+            const bool active = static_cast<uint32_t>(lane) < n_filtered;
+            exact_round(active ? lds.filtered[lane] : 0u, active, n_filtered);
+            n_filtered = 0;
+            wave_sync();
+        }
+    }
     PT_STAMP(st, 5);   // exact rounds
     const unsigned long long key = lds.best[lane];
     hit = (key == ~0ull) ? -1 : static_cast<int>(key & 0xFFFFFFFFu);
@@ -766,7 +807,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         atomicAdd(&a.stats[3], static_cast<unsigned long long>(wst.n_exact));
         atomicAdd(&a.stats[4], static_cast<unsigned long long>(n_miss));
         atomicAdd(&a.stats[5], static_cast<unsigned long long>(wst.w_segments));
-        atomicAdd(&a.stats[6], static_cast<unsigned long long>(wst.w_octets));
+        atomicAdd(&a.stats[6], static_cast<unsigned long long>(wst.w_node_rounds));
         atomicAdd(&a.stats[7], static_cast<unsigned long long>(wst.w_exact_iters));
 #ifdef PT_PHASE_TIMERS
         for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[8 + k], wst.phase[k]);

@@ -14,6 +14,8 @@ struct RenderArgs {
     const ClusterDesc *clusters;   // cull hierarchy (pt_scene.hpp: CullTables), read through the scalar cache
     const SphereRec *spheres;
     const CullRec *bary;
+    const CullRec *bary_all;        // big scenes: one record per triangle for the pair pre-filter, else nullptr
+    float a_max_all, m0_all, t_guard_all;
     const ExactRec *exact;    // n_tri
     const MatRec *mats;
     const uint8_t *sky;       // skybox texels (B,G,R bytes, top-down rows) or nullptr

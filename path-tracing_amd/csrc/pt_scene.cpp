@@ -399,6 +399,35 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     for (int k = 0; k < 16; ++k) out.spheres.push_back(never);
     for (int k = 0; k < 4; ++k) { CullRec c; std::memset(&c, 0, sizeof c); out.bary.push_back(c); }
 
+    // ---- big scenes: a barycentric record for every triangle, used to thin the (ray, triangle) pairs before the exact test
+    double a_max_all = 0, inv_2s_max_all = 0, diam2_2s_max_all = 0;
+    if (T > kBigSceneTriangles) {
+        out.bary_all.resize(static_cast<size_t>(T) + 4);
+        for (auto &c : out.bary_all) std::memset(&c, 0, sizeof c);
+        for (int k = 0; k < T; ++k) {
+            CullRec &c = out.bary_all[k];
+            const float *r = &s.tri[14 * static_cast<size_t>(k)];
+            const TriGeo &g = geo[k];
+            const V3 e1 = sub(g.v[1], g.v[0]), e2 = sub(g.v[2], g.v[0]);
+            const V3 nn = crs(e1, e2);
+            const double s2 = dt(nn, nn);
+            const V3 au = {crs(e2, nn).x / s2, crs(e2, nn).y / s2, crs(e2, nn).z / s2};
+            const V3 av = {crs(nn, e1).x / s2, crs(nn, e1).y / s2, crs(nn, e1).z / s2};
+            c.n[0] = r[0]; c.n[1] = r[1]; c.n[2] = r[2]; c.w = r[3];
+            c.au[0] = static_cast<float>(au.x); c.au[1] = static_cast<float>(au.y); c.au[2] = static_cast<float>(au.z);
+            c.av[0] = static_cast<float>(av.x); c.av[1] = static_cast<float>(av.y); c.av[2] = static_cast<float>(av.z);
+            c.cu = static_cast<float>(-dt(au, g.v[0]));
+            c.cv = static_cast<float>(-dt(av, g.v[0]));
+            if (g.degenerate) {
+                c.au[0] = c.au[1] = c.au[2] = c.av[0] = c.av[1] = c.av[2] = c.cu = c.cv = NAN;   // always kept
+            } else {
+                a_max_all = std::max(a_max_all, g.a_max);
+                inv_2s_max_all = std::max(inv_2s_max_all, 1.0 / (2.0 * g.area2));
+                diam2_2s_max_all = std::max(diam2_2s_max_all, g.diam * g.diam / (2.0 * g.area2));
+            }
+        }
+    }
+
     // ---- margins of the barycentric test (large triangles)
     const double m_abs = 2.0 * std::sqrt(3.0) * r_org;   // bound on |o.n| + |w|
     CullConstants &cc = out.cc;
@@ -410,6 +439,14 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     double tg = 4096.0 * r_org;
     if (a_max > 0) tg = std::min(tg, 1.0e6 / a_max);   // keep the reference's own area arithmetic meaningful
     cc.t_guard = static_cast<float>(tg);
+    // the same margins over ALL triangles (pair pre-filter of big scenes)
+    out.cc_all = cc;
+    out.cc_all.a_max = static_cast<float>(a_max_all * (1.0 + 1e-6));
+    out.cc_all.m0 = static_cast<float>(std::fabs(eps) * inv_2s_max_all * 1.01 + 40.0 * kU * diam2_2s_max_all
+                                       + 16.0 * kU * a_max_all * r_org * std::sqrt(3.0) + 1e-6);
+    double tga = 4096.0 * r_org;
+    if (a_max_all > 0) tga = std::min(tga, 1.0e6 / a_max_all);
+    out.cc_all.t_guard = static_cast<float>(tga);
 }
 
 }  // namespace pt

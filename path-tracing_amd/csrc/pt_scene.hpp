@@ -52,6 +52,7 @@ struct MatRec {
 static const int kChunk = 32;    // large class: triangles per candidate-mask word
 static const int kFan = 8;       // small class: children per node of the sphere tree
 static const int kMaxLevels = 8; // small class: tree levels per cluster (8^8 triangles)
+static const int kBigSceneTriangles = 2048;   // above this the kernel uses deep queues and pre-filters (ray, triangle) pairs
 
 // Bounding sphere used by the hierarchical cull: a ray is kept for the node iff its distance to `c` is <= sqrt(r2).
 // r2 already contains every slack that makes the test conservative (see DESIGN.md "Culling").
@@ -83,6 +84,8 @@ struct CullConstants {
 struct CullTables {
     std::vector<SphereRec> spheres;
     std::vector<CullRec> bary;
+    std::vector<CullRec> bary_all;   // big scenes only: a barycentric record for EVERY triangle (pair pre-filter)
+    CullConstants cc_all;            // its margins (they must cover the smallest triangle of the scene)
     std::vector<ClusterDesc> clusters;
     CullConstants cc;
     float eps = 0;

@@ -8,4 +8,4 @@ for n in (64,):
     s = pt.Scene.load_obj(tmp, f"x{n}.obj", 0)
     r = s.render_host(1920, 1080, 8, 8)
     st = r[3]; ws = st["wave_segments"]
-    print(n, st["kernel_ms"], "Ms/s", 1920*1080*8/st["kernel_ms"]/1e3, "octet rounds/wseg", st["wave_octets"]/ws, "exact rounds/wseg", st["wave_exact_iterations"]/ws, "exact/seg", st["exact_tests"]/st["segments"])
+    print(n, st["kernel_ms"], "Ms/s", 1920*1080*8/st["kernel_ms"]/1e3, "node rounds/wseg", st["wave_node_rounds"]/ws, "exact rounds/wseg", st["wave_exact_iterations"]/ws, "exact/seg", st["exact_tests"]/st["segments"])
