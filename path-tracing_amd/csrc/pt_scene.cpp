@@ -314,7 +314,8 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         rec.c[0] = static_cast<float>(c.x); rec.c[1] = static_cast<float>(c.y); rec.c[2] = static_cast<float>(c.z);
         // the centre is rounded to float: grow by that displacement
         const double c_round = nrm(sub(c, V3{rec.c[0], rec.c[1], rec.c[2]}));
-        const double r2 = (reff + c_round) * (reff + c_round) * (1.0 + 1e-6) + disc_err;
+        double r2 = (reff + c_round) * (reff + c_round) * (1.0 + 1e-6) + disc_err;
+        if (const char *e = std::getenv("PT_MUTATE_SPHERE_R2")) r2 *= std::atof(e);   // mutation testing only
         rec.r2 = (inf || !std::isfinite(r2)) ? INFINITY : static_cast<float>(r2 * (1.0 + 2e-7));
         return inf ? INFINITY : reff;
     };

@@ -1,0 +1,64 @@
+"""BASELINE.json's full-size configuration (Tor.obj 1920x1080 x 64 spp x MRR 8) on the GPU: size-independent
+properties of the whole frame, plus a bit-exact comparison of sampled rows against the oracle (which can render any
+row band of the same frame, because the counter RNG is keyed by the global pixel index)."""
+import hashlib
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pt = importlib.import_module("path-tracing_amd")
+pytestmark = pytest.mark.gpu
+W, H, SPP, MRR = 1920, 1080, 64, 8
+
+
+@pytest.fixture(scope="module")
+def frame(models_dir):
+    g = pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+    s, s2, c, st = g.render_host(W, H, SPP, MRR, error=-1.0, seed=42)
+    return g, s, s2, c, st
+
+
+def test_counts_are_conserved(frame):
+    g, s, s2, c, st = frame
+    assert st["samples_traced"] == W * H * SPP
+    assert st["segments"] <= MRR * st["samples_traced"] and st["segments"] > 7.5 * st["samples_traced"]
+    assert st["contributing"] == int(c.sum())                 # every counted sample is in exactly one pixel's count
+    assert 0.005 < st["contributing"] / st["samples_traced"] < 0.02
+    assert (s >= 0).all() and (s2 >= 0).all() and (s2 <= s + 1e-3).all()      # contributions are <= 1 per sample
+    assert ((c == 0) == (s.sum(1) == 0)).mean() > 0.9999
+
+
+def test_frame_is_deterministic_and_tiling_independent(frame):
+    g, s, s2, c, st = frame
+    digest = hashlib.sha256(s.tobytes() + s2.tobytes() + c.tobytes()).hexdigest()
+    # the same frame again, as three row bands of different heights and as four pass slices
+    parts = [g.render_host(W, H, SPP, MRR, rows=r)[:3] for r in [(0, 333), (333, 334), (334, 1080)]]
+    bs, bs2, bc = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    assert hashlib.sha256(bs.tobytes() + bs2.tobytes() + bc.tobytes()).hexdigest() == digest
+    acc = None
+    for p0, n in [(0, 1), (1, 30), (31, 16), (47, 17)]:
+        acc = g.render_host(W, H, n, MRR, pass_begin=p0, accum=acc)[:3]
+    assert hashlib.sha256(acc[0].tobytes() + acc[1].tobytes() + acc[2].tobytes()).hexdigest() == digest
+
+
+def test_sampled_rows_match_the_oracle(frame, oracle_scene):
+    g, s, s2, c, st = frame
+    for r0 in (0, 411, 540, 1078):        # top edge, torus, centre, bottom edge
+        rs, rs2, rc, _ = O.render(oracle_scene, W, H, SPP, MRR, rows=(r0, r0 + 2), error=-1.0, seed=42)
+        sl = slice(r0 * W, (r0 + 2) * W)
+        assert np.array_equal(c[sl], rc)
+        assert np.array_equal(s[sl].view(np.uint32), rs.view(np.uint32))
+        assert np.array_equal(s2[sl].view(np.uint32), rs2.view(np.uint32))
+
+
+def test_image_is_plausible(frame):
+    g, s, s2, c, st = frame
+    bgr, disp = pt.resolve(W, H, s, s2, c)
+    img = bgr.reshape(H, W, 3).astype(np.float64)
+    assert img[40:66, 900:1040].mean() > 200            # the light source at the top centre is saturated
+    left, right = img[300:800, 20:120].mean((0, 1)), img[300:800, 1800:1900].mean((0, 1))
+    assert left[2] > 2 * left[1] and right[1] > 2 * right[2]       # red wall on the left, green on the right (B,G,R order)
+    assert 0.5 < disp[2] < 0.9 and disp[0] < 1.5
