@@ -168,7 +168,10 @@ def main():
         seg = sum(s["segments"] for s in stats) / k
         kms = kernel_ms_rank0 / k
         achieved = seg * n_tri * FLOP_PER_TEST / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        algo_bytes = npx * 28 * 2 + n_tri * 112          # accumulators read + written once per launch, scene tables once
+        # accumulators are read + written once per pass-range chunk of a tile (the launch is cut into chunks for tail
+        # balance, DESIGN.md "Scheduling"), scene tables once
+        n_chunks = max(1, stats[0].get("n_chunks", 1))
+        algo_bytes = npx * 28 * 2 * n_chunks + n_tri * 112
         traffic = valu_util = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")   # written by tools/summarize_pmc.py from rocprofv3 --pmc passes
         if world == 1 and os.path.exists(pmc):
@@ -197,7 +200,7 @@ def main():
                          "kernel": "pt::integrate_kernel<false,false>", "kernel_ms": kms,
                          "valu_issue_utilisation_pmc": valu_util, "segments_per_launch": seg,
                          "flop_per_test": FLOP_PER_TEST,
-                         "hbm": {"algorithmic_bytes": algo_bytes, "achieved": algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                         "hbm": {"algorithmic_bytes": algo_bytes, "chunks_per_tile": n_chunks, "achieved": algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": (algo_bytes / (kms * 1e-3) / 1e9) / PEAK_HBM_GBS if kms > 0 else 0.0}},
         }

@@ -76,6 +76,8 @@ typedef struct pt_render_stats {
     uint64_t wave_exact_iterations; /* wave-level: rounds of the lane-balanced exact tests */
     float kernel_ms;                /* HIP-event time of the integrator kernel on the launch stream; <0 if not timed */
     int32_t n_triangles;
+    int32_t n_chunks;               /* pass-range chunks per pixel tile in this launch (each reads + writes the tile once) */
+    int32_t reserved;
 } pt_render_stats;
 
 /* ---- scene ---------------------------------------------------------------------------------------- */

@@ -325,10 +325,10 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
     a.eps = p->eps; a.error = p->error; a.seed = p->seed;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
-    a.blocks_x = (p->width + 7) / 8;
+    a.blocks_x = (p->width + pt::kTileW - 1) / pt::kTileW;
     // Scheduler: cut the pass range into chunks so that the launch has enough work items to balance its tail
     // (about 24 per wave slot of the chip), but keep chunks of at least 4 passes.
-    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + 7) / 8);
+    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
     if (n_tiles == 0) return PT_OK;
     const uint32_t slots = 256u * 4u * 6u;
     uint32_t per_slot = 24u;
@@ -373,6 +373,8 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
         stats->wave_exact_iterations = h[7];
         stats->kernel_ms = ms;
         stats->n_triangles = scene->host.n_tri();
+        stats->n_chunks = static_cast<int32_t>(n_chunks);
+        stats->reserved = 0;
 #ifdef PT_PHASE_TIMERS
         std::fprintf(stderr, "PT_PHASE_TIMERS cycles:");
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[8 + k]);

@@ -597,8 +597,8 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
-    const int x = static_cast<int>(tile % a.blocks_x) * 8 + (lane & 7);
-    const int y = a.row_begin + static_cast<int>(tile / a.blocks_x) * 8 + (lane >> 3);
+    const int x = static_cast<int>(tile % a.blocks_x) * kTileW + (lane % kTileW);
+    const int y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH + (lane / kTileW);
     const bool in_image = x < a.width && y < a.row_end;
     const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
     const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
@@ -785,7 +785,40 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         }
     }
 
-    if (in_image) {
+    // Write-back.  A tile whose rows are 16-byte aligned in the caller's planes is written with one 16-byte store per lane
+    // (a row of the tile is kTileW*12 contiguous bytes of sum / sum2 and kTileW*4 of count): dword stores at a 12-byte
+    // stride made the memory side see about twice the bytes.
+    const int tile_x = static_cast<int>(tile % a.blocks_x) * kTileW, tile_y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;
+    const bool whole = (a.width % 4 == 0) && tile_x + kTileW <= a.width && tile_y + kTileH <= a.row_end;   // wave-uniform
+    wave_sync();
+    if (whole) {
+        constexpr int kRowVec = kTileW * 3 / 4;          // float4 per tile row of a colour plane
+        if (lane < kRowVec * kTileH) {
+            const int row = lane / kRowVec, v = lane % kRowVec;
+            const size_t base = (static_cast<size_t>(tile_y - a.row_begin + row) * a.width + tile_x) * 3 + 4 * v;
+            float4 o1, o2;
+            float *p1 = &o1.x, *p2 = &o2.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * v + j;                   // element of the row: pixel e/3, channel e%3
+                p1[j] = lds.acc[e % 3][row * kTileW + e / 3];
+                p2[j] = lds.acc[3 + e % 3][row * kTileW + e / 3];
+            }
+            *reinterpret_cast<float4 *>(a.sum + base) = o1;
+            *reinterpret_cast<float4 *>(a.sum2 + base) = o2;
+        }
+        constexpr int kCntVec = kTileW / 4;              // int4 per tile row of the count plane
+        if (lane < kCntVec * kTileH) {
+            const int row = lane / kCntVec, v = lane % kCntVec;
+            const size_t base = static_cast<size_t>(tile_y - a.row_begin + row) * a.width + tile_x + 4 * v;
+            int4 oc;
+            oc.x = __float_as_int(lds.acc[6][row * kTileW + 4 * v]);
+            oc.y = __float_as_int(lds.acc[6][row * kTileW + 4 * v + 1]);
+            oc.z = __float_as_int(lds.acc[6][row * kTileW + 4 * v + 2]);
+            oc.w = __float_as_int(lds.acc[6][row * kTileW + 4 * v + 3]);
+            *reinterpret_cast<int4 *>(a.count + base) = oc;
+        }
+    } else if (in_image) {
         const size_t pe = static_cast<size_t>(y - a.row_begin) * a.width + x;   // recomputed: p would be spilled across the kernel
 #pragma unroll
         for (int k = 0; k < 3; ++k) {

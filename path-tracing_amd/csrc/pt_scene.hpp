@@ -52,6 +52,11 @@ struct MatRec {
 static const int kChunk = 32;    // large class: triangles per candidate-mask word
 static const int kFan = 8;       // small class: children per node of the sphere tree
 static const int kMaxLevels = 8; // small class: tree levels per cluster (8^8 triangles)
+// Pixel tile of one wave: kTileW x kTileH = 64 pixels.
+#ifndef PT_TILE_W
+#define PT_TILE_W 8
+#endif
+static const int kTileW = PT_TILE_W, kTileH = 64 / PT_TILE_W;
 static const int kBigSceneTriangles = 2048;   // above this the kernel uses deep queues and pre-filters (ray, triangle) pairs
 
 // Bounding sphere used by the hierarchical cull: a ray is kept for the node iff its distance to `c` is <= sqrt(r2).

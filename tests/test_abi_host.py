@@ -33,7 +33,7 @@ def test_header_symbols_are_exported():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(pt.RenderParams) == 40
-    assert C.sizeof(pt.RenderStats) == 72
+    assert C.sizeof(pt.RenderStats) == 80
 
 
 def test_loader_matches_oracle_bit_for_bit(models_dir, oracle_scene):
