@@ -62,8 +62,8 @@ def main():
                                         "ratio": counters["FETCH_SIZE"] * 1024 / known_reads, "scale_applied": a.fetch_scale}
         summary["note"] = ("FETCH_SIZE/WRITE_SIZE in KiB from separate --pmc passes.  MI355X_MICROARCH.md: FETCH_SIZE halves WIDE "
                            "streaming reads and other widths must be calibrated on a known byte count: this kernel's reads are the "
-                           "accumulators (28 B/pixel per chunk, 4-byte strided loads), and FETCH_SIZE counts them about 1:1, so no x2 "
-                           "is applied.  WRITE_SIZE = the accumulator write-backs (28 B/pixel per chunk, 16-byte stores) plus one 64-byte "
+                           "accumulators (28 B/pixel per chunk, 4-byte strided loads); FETCH_SIZE counts 0.76-1.0 of them (1.00 measured with "
+                           "4 chunks, 0.76 with 5: a chunk's re-read can hit the L2 that wrote the tile back), so no x2 is applied.  WRITE_SIZE = the accumulator write-backs (28 B/pixel per chunk, 16-byte stores) plus one 64-byte "
                            "request for each of the ~10 atomics / flag stores a work item issues (ticket, hand-off flag, 8 statistics "
                            "counters).")
     if "SQ_INSTS_VALU" in counters and "GRBM_GUI_ACTIVE" in counters:
