@@ -38,6 +38,7 @@ struct pt_scene {
     pt::ExactRec *d_exact = nullptr;
     pt::MatRec *d_mats = nullptr;
     unsigned long long *d_stats = nullptr;
+    int cu_count = 256;            // compute units of the scene's device
     uint32_t *d_sched = nullptr;   // ticket + per-tile chunk counters of the integrator's scheduler
     size_t sched_words = 0;
     std::vector<uint8_t> sky;   // skybox texels (B,G,R; top-down rows; no padding), empty = none
@@ -74,6 +75,8 @@ int upload(pt_scene *s, int device) {
     if (device >= n) return fail(PT_ERR_NO_DEVICE, "device ordinal " + std::to_string(device) + " out of range");
     s->device = device;
     PT_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->cu_count = prop.multiProcessorCount;
     const auto &t = s->tables;
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_exact), t.exact.size() * sizeof(pt::ExactRec) + 64));
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_mats), t.mats.size() * sizeof(pt::MatRec) + 64));
@@ -138,6 +141,26 @@ int finish_scene(pt_scene *s, int device, pt_scene **out) {
     }
     *out = s;
     return PT_OK;
+}
+
+// The part of the kernel arguments that describes the scene (its tables for the current eps).
+void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
+    std::memset(&a, 0, sizeof a);
+    const pt::CullConstants &cc = scene->cull.host.cc, &ca = scene->cull.host.cc_all;
+    a.clusters = scene->cull.clusters;
+    a.spheres = scene->cull.spheres;
+    a.bary = scene->cull.bary;
+    a.bary_all = scene->cull.bary_all;
+    a.a_max_all = ca.a_max; a.m0_all = ca.m0; a.t_guard_all = ca.t_guard;
+    a.exact = scene->d_exact;
+    a.mats = scene->d_mats;
+    a.sky = scene->d_sky;
+    a.sky_w = scene->sky_w;
+    a.sky_h = scene->sky_h;
+    a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
+    a.n_tri = scene->host.n_tri();
+    a.eps = eps;
+    a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
 }
 
 int check_params(const pt_scene *scene, const pt_render_params *p) {
@@ -301,36 +324,27 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const int crc = ensure_cull(scene, p->eps);
     if (crc != PT_OK) return crc;
-    const pt::CullConstants cc = scene->cull.host.cc;
     pt::RenderArgs a;
-    a.clusters = scene->cull.clusters;
-    a.spheres = scene->cull.spheres;
-    a.bary = scene->cull.bary;
-    a.bary_all = scene->cull.bary_all;
-    a.a_max_all = scene->cull.host.cc_all.a_max;
-    a.m0_all = scene->cull.host.cc_all.m0;
-    a.t_guard_all = scene->cull.host.cc_all.t_guard;
-    a.exact = scene->d_exact;
-    a.mats = scene->d_mats;
-    a.sky = scene->d_sky;
-    a.sky_w = scene->sky_w;
-    a.sky_h = scene->sky_h;
+    fill_scene_args(scene, p->eps, a);
     a.sum = d_sum;
     a.sum2 = d_sum2;
     a.count = d_count;
     a.stats = stats ? scene->d_stats : nullptr;
-    a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
-    a.n_tri = scene->host.n_tri();
     a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
     a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
-    a.eps = p->eps; a.error = p->error; a.seed = p->seed;
-    a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
+    a.error = p->error; a.seed = p->seed;
     a.blocks_x = (p->width + pt::kTileW - 1) / pt::kTileW;
     // Scheduler: cut the pass range into chunks so that the launch has enough work items to balance its tail
     // (about 24 per wave slot of the chip), but keep chunks of at least 4 passes.
     const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
-    if (n_tiles == 0) return PT_OK;
-    const uint32_t slots = 256u * 4u * 6u;
+    if (n_tiles == 0) {
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+            stats->n_triangles = scene->host.n_tri();
+        }
+        return PT_OK;
+    }
+    const uint32_t slots = static_cast<uint32_t>(scene->cu_count) * 4u * 6u;   // CUs x SIMDs x waves per SIMD of this kernel
     uint32_t per_slot = 24u;
     if (const char *e = std::getenv("PT_ITEMS_PER_SLOT")) per_slot = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // tuning knob
     uint32_t n_chunks = (per_slot * slots + n_tiles - 1u) / n_tiles;
@@ -394,22 +408,8 @@ int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, co
     PT_HIP_TRY(hipSetDevice(scene->device));
     const int crc = ensure_cull(scene, eps);
     if (crc != PT_OK) return crc;
-    const pt::CullConstants cc = scene->cull.host.cc;
     pt::RenderArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.clusters = scene->cull.clusters;
-    a.spheres = scene->cull.spheres;
-    a.bary = scene->cull.bary;
-    a.bary_all = scene->cull.bary_all;
-    a.a_max_all = scene->cull.host.cc_all.a_max;
-    a.m0_all = scene->cull.host.cc_all.m0;
-    a.t_guard_all = scene->cull.host.cc_all.t_guard;
-    a.exact = scene->d_exact;
-    a.mats = scene->d_mats;
-    a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
-    a.n_tri = scene->host.n_tri();
-    a.eps = eps;
-    a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
+    fill_scene_args(scene, eps, a);
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     int32_t *d_i = nullptr;
     const size_t n = static_cast<size_t>(n_rays);
