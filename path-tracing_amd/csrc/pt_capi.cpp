@@ -160,7 +160,7 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
     a.n_tri = scene->host.n_tri();
     a.eps = eps;
-    a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.t_guard = cc.t_guard;
+    a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.m0_quad = cc.m0_quad; a.t_guard = cc.t_guard;
 }
 
 int check_params(const pt_scene *scene, const pt_render_params *p) {

@@ -164,6 +164,28 @@ __device__ __forceinline__ bool sphere_keep(float cx, float cy, float cz, float 
     return !(disc > r2);
 }
 
+// A quad record = the two halves of a parallelogram in one stored plane (pt_scene.hpp: ClusterDesc): the plane rows
+// as in a triangle record, then alpha and beta rows.  Half A keeps iff min(beta, alpha-beta, 1-alpha) >= -mg,
+// half B iff min(alpha, beta-alpha, 1-beta) >= -mg.  Returns bit 0 = reject A, bit 1 = reject B.
+__device__ __forceinline__ uint32_t cull_reject_quad(const CullRec r, const Ray &q, float k1, float k2, float a_max, float m0q,
+                                                     float t_guard) {
+    const float num = __builtin_fmaf(q.ox, r.n[0], __builtin_fmaf(q.oy, r.n[1], __builtin_fmaf(q.oz, r.n[2], r.w)));
+    const float den = __builtin_fmaf(q.dx, r.n[0], __builtin_fmaf(q.dy, r.n[1], q.dz * r.n[2]));
+    const float rden = __builtin_amdgcn_rcpf(den);
+    const float t = -num * rden;
+    const float px = __builtin_fmaf(t, q.dx, q.ox), py = __builtin_fmaf(t, q.dy, q.oy), pz = __builtin_fmaf(t, q.dz, q.oz);
+    const float al = __builtin_fmaf(px, r.au[0], __builtin_fmaf(py, r.au[1], __builtin_fmaf(pz, r.au[2], r.cu)));
+    const float be = __builtin_fmaf(px, r.av[0], __builtin_fmaf(py, r.av[1], __builtin_fmaf(pz, r.av[2], r.cv)));
+    const float d = al - be;
+    const float ea = __builtin_fminf(__builtin_fminf(be, d), 1.0f - al);
+    const float eb = __builtin_fminf(__builtin_fminf(al, -d), 1.0f - be);
+    const float et = __builtin_fmaf(k1, __builtin_fabsf(t), k2) * __builtin_fabsf(rden);
+    const float mg = __builtin_fmaf(a_max, et, m0q);
+    const bool behind = t < -et;
+    const bool trusted = __builtin_fabsf(t) < t_guard;
+    return ((trusted & ((ea < -mg) | behind)) ? 1u : 0u) | ((trusted & ((eb < -mg) | behind)) ? 2u : 0u);
+}
+
 __device__ __forceinline__ bool cull_reject(const CullRec r, const Ray &q, float k1, float k2, float a_max, float m0,
                                             float t_guard) {
     const float num = __builtin_fmaf(q.ox, r.n[0], __builtin_fmaf(q.oy, r.n[1], __builtin_fmaf(q.oz, r.n[2], r.w)));
@@ -527,18 +549,24 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             // ---- large triangles: barycentric cull, wave-uniform over the triangles.
             // The margins go to VGPRs here: a VALU instruction can name only one SGPR, so an SGPR-resident
             // constant next to an SGPR-resident triangle coefficient would cost a v_mov per use.
-            float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, t_guard = a.t_guard;
-            asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(t_guard));
+            float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, m0q = a.m0_quad, t_guard = a.t_guard;
+            asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(m0q), "+v"(t_guard));
             const int n_words = static_cast<int>((n_tri + kChunk - 1) / kChunk);
             for (int w = 0; w < n_words; ++w) {
                 const uint32_t left = n_tri - kChunk * w;
                 const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
+                const uint32_t quads = w < kMaxLevels - 1 ? ((ConstU)cp)[9 + w] : 0u;   // bit k: slots k, k+1 are one quad record
                 uint32_t m = 0;
                 for (uint32_t k0 = 0; k0 < min(left, 32u); k0 += 2) {   // records are padded to whole words
+                    if ((quads >> k0) & 1u) {   // wave-uniform
+                        const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
+                        m |= (~rej & 3u) << k0;
+                    } else {
 #pragma unroll
-                    for (uint32_t j = 0; j < 2; ++j) {
-                        const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
-                        m |= rej ? 0u : (1u << (k0 + j));
+                        for (uint32_t j = 0; j < 2; ++j) {
+                            const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
+                            m |= rej ? 0u : (1u << (k0 + j));
+                        }
                     }
                 }
                 m = pc ? m : 0u;

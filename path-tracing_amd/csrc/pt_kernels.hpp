@@ -28,7 +28,7 @@ struct RenderArgs {
     int32_t pass_begin, pass_count, mrr;
     float eps, error;
     uint32_t seed;
-    float k1, k2, a_max, m0, t_guard;   // cull margins (pt_scene.hpp: CullConstants)
+    float k1, k2, a_max, m0, m0_quad, t_guard;   // cull margins (pt_scene.hpp: CullConstants)
     int32_t blocks_x;                   // ceil(width / 8)
     uint32_t *sched;                    // [0] ticket counter, [1 + tile] chunks of that tile already published; zeroed per launch
     uint32_t n_tiles, n_chunks;         // work items = n_tiles * n_chunks, chunk-major

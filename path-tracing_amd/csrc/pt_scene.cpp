@@ -322,7 +322,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
 
     // ---- classes: a triangle whose own sphere is a sizeable part of the scene is culled by the barycentric test
     std::vector<uint8_t> large(T);
-    double a_max = 0, inv_2s_max = 0, diam2_2s_max = 0;
+    double a_max = 0, inv_2s_max = 0, diam2_2s_max = 0, quad_slack = 0;
     for (int i = 0; i < T; ++i) {
         SphereRec tmp;
         const double reff = sphere_of(i, 1, tmp);
@@ -392,6 +392,80 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
                 }
                 out.bary.push_back(c);
             }
+            // Quads: two consecutive large triangles (even slot first) that lie in ONE stored plane and share an edge
+            // are the two halves of a (near-)parallelogram s0, a, s1, b with diagonal s0-s1.  With P = s0 + alpha*(a-s0) +
+            // beta*(b-s0), half A = (s0, s1, a) has barycentrics (beta, alpha-beta, 1-alpha) and half B = (s0, s1, b) has
+            // (alpha, beta-alpha, 1-beta), so ONE plane evaluation and two affine rows cull both.  The identity is exact
+            // only for an exact parallelogram; the deviation of each half's own barycentrics from it is measured below
+            // over the region alpha, beta in [-1, 2] and added to the margin (quad_slack); pairs that deviate by more
+            // than 1 % are left as two triangles.  (Outside that region the derived minimum is <= -1 and the deviation
+            // grows at most linearly, so a far point can never be kept by one test and rejected by the other.)
+            for (int w = 0; w < n_words && w < kMaxLevels - 1; ++w) {
+                uint32_t qmask = 0;
+                for (int k = w * kChunk; k + 1 < std::min(n, (w + 1) * kChunk); k += 2) {
+                    const float *ra = &s.tri[14 * static_cast<size_t>(i + k)], *rb = &s.tri[14 * static_cast<size_t>(i + k + 1)];
+                    if (std::memcmp(ra, rb, 16) != 0 || geo[i + k].degenerate || geo[i + k + 1].degenerate) continue;
+                    // shared vertices (bitwise) and the two apexes
+                    int sa[2], sb[2], ns = 0, apex_a = -1, apex_b = -1;
+                    bool used_b[3] = {false, false, false};
+                    for (int x = 0; x < 3; ++x) {
+                        int match = -1;
+                        for (int y = 0; y < 3; ++y)
+                            if (!used_b[y] && std::memcmp(ra + 4 + 3 * x, rb + 4 + 3 * y, 12) == 0) { match = y; break; }
+                        if (match >= 0 && ns < 2) { sa[ns] = x; sb[ns] = match; used_b[match] = true; ++ns; }
+                        else apex_a = x;
+                    }
+                    if (ns != 2 || apex_a < 0) continue;
+                    for (int y = 0; y < 3; ++y) if (!used_b[y]) apex_b = y;
+                    const TriGeo &ga = geo[i + k], &gb = geo[i + k + 1];
+                    const V3 s0 = ga.v[sa[0]], s1 = ga.v[sa[1]], pa = ga.v[apex_a], pb = gb.v[apex_b];
+                    const V3 ea = sub(pa, s0), eb = sub(pb, s0);
+                    const V3 nn = crs(ea, eb);
+                    const double s2 = dt(nn, nn);
+                    if (!(s2 > 0)) continue;
+                    const V3 ral = {crs(eb, nn).x / s2, crs(eb, nn).y / s2, crs(eb, nn).z / s2};   // alpha row: dual of ea
+                    const V3 rbe = {crs(nn, ea).x / s2, crs(nn, ea).y / s2, crs(nn, ea).z / s2};   // beta row: dual of eb
+                    const double cal = -dt(ral, s0), cbe = -dt(rbe, s0);
+                    // true barycentrics of each half (orthogonal projection onto its own plane), as affine functions
+                    auto bary_rows = [&](const TriGeo &g, int i0, int i1, int i2, V3 rows[3], double cst[3]) {
+                        const V3 e1 = sub(g.v[i1], g.v[i0]), e2 = sub(g.v[i2], g.v[i0]);
+                        const V3 m = crs(e1, e2);
+                        const double q = dt(m, m);
+                        rows[1] = {crs(e2, m).x / q, crs(e2, m).y / q, crs(e2, m).z / q};   // weight of i1
+                        rows[2] = {crs(m, e1).x / q, crs(m, e1).y / q, crs(m, e1).z / q};   // weight of i2
+                        rows[0] = {-(rows[1].x + rows[2].x), -(rows[1].y + rows[2].y), -(rows[1].z + rows[2].z)};
+                        cst[1] = -dt(rows[1], g.v[i0]); cst[2] = -dt(rows[2], g.v[i0]); cst[0] = 1.0 - cst[1] - cst[2];
+                    };
+                    V3 rowa[3], rowb[3];
+                    double ca[3], cb[3];
+                    bary_rows(ga, sa[0], sa[1], apex_a, rowa, ca);   // weights of s0, s1, a
+                    bary_rows(gb, sb[0], sb[1], apex_b, rowb, cb);   // weights of s0, s1, b
+                    const V3 nu = {nn.x / std::sqrt(s2), nn.y / std::sqrt(s2), nn.z / std::sqrt(s2)};
+                    const double hh = 0.05 * std::max(ga.diam, gb.diam);
+                    double dev = 0;
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        const double al = (c8 & 1) ? 2.0 : -1.0, be = (c8 & 2) ? 2.0 : -1.0, h = (c8 & 4) ? hh : -hh;
+                        const V3 P = {s0.x + al * ea.x + be * eb.x + h * nu.x, s0.y + al * ea.y + be * eb.y + h * nu.y, s0.z + al * ea.z + be * eb.z + h * nu.z};
+                        const double a_ = dt(ral, P) + cal, b_ = dt(rbe, P) + cbe;
+                        const double da[3] = {1 - a_, b_, a_ - b_}, db[3] = {1 - b_, a_, b_ - a_};   // derived weights of (s0, s1, apex)
+                        for (int t3 = 0; t3 < 3; ++t3) {
+                            dev = std::max(dev, std::fabs(dt(rowa[t3], P) + ca[t3] - da[t3]));
+                            dev = std::max(dev, std::fabs(dt(rowb[t3], P) + cb[t3] - db[t3]));
+                        }
+                    }
+                    if (!(dev < 0.01)) continue;
+                    quad_slack = std::max(quad_slack, dev);
+                    a_max = std::max(a_max, std::max(nrm(ral), std::max(nrm(rbe), nrm(sub(ral, rbe)))));
+                    CullRec &q = out.bary[cd.data_off + k];
+                    q.au[0] = static_cast<float>(ral.x); q.au[1] = static_cast<float>(ral.y); q.au[2] = static_cast<float>(ral.z);
+                    q.av[0] = static_cast<float>(rbe.x); q.av[1] = static_cast<float>(rbe.y); q.av[2] = static_cast<float>(rbe.z);
+                    q.cu = static_cast<float>(cal);
+                    q.cv = static_cast<float>(cbe);
+                    std::memset(&out.bary[cd.data_off + k + 1], 0, sizeof(CullRec));
+                    qmask |= 1u << (k - w * kChunk);
+                }
+                cd.level_off[w] = qmask;   // large clusters have no sphere tree: the slots carry the quad masks
+            }
         }
         out.clusters.push_back(cd);
         i += n;
@@ -440,6 +514,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     double tg = 4096.0 * r_org;
     if (a_max > 0) tg = std::min(tg, 1.0e6 / a_max);   // keep the reference's own area arithmetic meaningful
     cc.t_guard = static_cast<float>(tg);
+    cc.m0_quad = static_cast<float>(static_cast<double>(cc.m0) + quad_slack * 1.01 + 8.0 * kU * a_max * r_org);
     // the same margins over ALL triangles (pair pre-filter of big scenes)
     out.cc_all = cc;
     out.cc_all.a_max = static_cast<float>(a_max_all * (1.0 + 1e-6));

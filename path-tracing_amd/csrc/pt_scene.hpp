@@ -70,6 +70,8 @@ struct SphereRec {
 //       with spheres that keep nothing.  Level L starts at SphereRec index data_off + level_off[L] (level_off[0] = 0);
 //       the top level (n_levels - 1) has at most 8 nodes.
 //   kind 1 (large triangles): data_off indexes CullRec, one barycentric cull record per triangle, padded to 32.
+//       level_off[w] is then the QUAD MASK of word w (w < 7): bit k set = slots k, k+1 hold one quad record (plane,
+//       alpha row, beta row) for triangles k and k+1, two halves of a parallelogram in one stored plane.
 struct ClusterDesc {
     float c[3], r2;                                  // bounding sphere of the whole run
     uint32_t first_tri, n_tri, kind, data_off;
@@ -82,6 +84,7 @@ struct CullConstants {
     float k1, k2;     // |t_cull - t_reference| <= (k2 + k1*|t|) / |n.d|
     float a_max;      // scales a distance error into barycentric units
     float m0;         // barycentric slack an accepted point can have (eps / area, float error of the area sum)
+    float m0_quad;    // m0 + the deviation of fused quads from exact parallelograms
     float t_guard;    // beyond this |t| the cull test abstains
 };
 

@@ -114,3 +114,48 @@ def test_tables_depend_on_eps(tor):
     a, b = tor.cull_tables(1e-4), tor.cull_tables(1e-2)
     assert (b["spheres"][:, 3] >= a["spheres"][:, 3]).all()
     assert b["constants"]["m0"] > a["constants"]["m0"]
+
+
+def test_quads_of_the_room_are_fused_and_never_cull_an_accepted_hit(tor, oracle_scene):
+    """Large class: consecutive coplanar triangle pairs share one quad record (plane, alpha row, beta row).  Every
+    (ray, wall triangle) pair the reference accepts must satisfy the quad test with the margins the kernel uses."""
+    import ctypes as C
+    t = tor.cull_tables()
+    large = np.flatnonzero(t["kind"] == 1)
+    assert [int(t["level_off"][c][1]) for c in large] == [1, 0b101010101]      # quad masks of word 0: every wall pair fused
+    k1, k2, a_max, m0 = (t["constants"][k] for k in ("k1", "k2", "a_max", "m0"))
+    tri, _ = tor.triangles()
+    v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
+    rng = np.random.default_rng(23)
+    L = O.lib()
+    best = C.c_float()
+    checked = 0
+    for c in large:
+        first, n, off, mask = t["first_tri"][c], t["n_tri"][c], t["data_off"][c], int(t["level_off"][c][1])
+        for k in range(0, n, 2):
+            assert (mask >> k) & 1
+            rec = t["bary"][off + k].astype(np.float64)
+            for half in (0, 1):
+                ti = first + k + half
+                w = rng.dirichlet([0.5, 0.5, 0.5], 3000) * rng.choice([1.0, 1.0, 1.0005], 3000)[:, None]   # incl. edges / just outside
+                target = (v[ti] * w[:, :, None]).sum(1)
+                org = rng.uniform([-9.5, -9.5, -20.5], [9.5, 9.5, 9.5], (3000, 3))
+                d = (target - org).astype(np.float32)
+                inv = np.float32(1) / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
+                d = d * inv[:, None]
+                o32 = org.astype(np.float32)
+                for i in range(len(o32)):
+                    st = L.orc_probe_intersect(oracle_scene.h, int(ti), o32[i].ctypes.data_as(C.POINTER(C.c_float)),
+                                               d[i].ctypes.data_as(C.POINTER(C.c_float)), 1e-4, np.float32(np.inf), C.byref(best))
+                    if st != 4:
+                        continue
+                    checked += 1
+                    o64, d64 = o32[i].astype(np.float64), d[i].astype(np.float64)
+                    num, den = rec[0:3] @ o64 + rec[3], rec[0:3] @ d64
+                    tt = -num / den
+                    P = o64 + tt * d64
+                    al, be = rec[4:7] @ P + rec[7], rec[8:11] @ P + rec[11]
+                    e = min(be, al - be, 1 - al) if half == 0 else min(al, be - al, 1 - be)
+                    et = (k1 * abs(tt) + k2) / abs(den)
+                    assert e >= -(a_max * et + m0) and tt >= -et, (ti, e, tt)
+    assert checked > 10000
