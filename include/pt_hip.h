@@ -77,7 +77,7 @@ typedef struct pt_render_stats {
     float kernel_ms;                /* HIP-event time of the integrator kernel on the launch stream; <0 if not timed */
     int32_t n_triangles;
     int32_t n_chunks;               /* pass-range chunks per pixel tile in this launch (each reads + writes the tile once) */
-    int32_t reserved;
+    int32_t partial_commit_rounds;  /* wave-level: tree-walk rounds that could not commit all 64 lanes (queues full) */
 } pt_render_stats;
 
 /* ---- scene ---------------------------------------------------------------------------------------- */

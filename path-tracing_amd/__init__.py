@@ -45,7 +45,7 @@ class RenderStats(C.Structure):
     _fields_ = [("samples_traced", C.c_uint64), ("segments", C.c_uint64), ("contributing", C.c_uint64),
                 ("exact_tests", C.c_uint64), ("misses", C.c_uint64), ("wave_segments", C.c_uint64),
                 ("wave_node_rounds", C.c_uint64), ("wave_exact_iterations", C.c_uint64), ("kernel_ms", C.c_float),
-                ("n_triangles", C.c_int32), ("n_chunks", C.c_int32), ("reserved", C.c_int32)]
+                ("n_triangles", C.c_int32), ("n_chunks", C.c_int32), ("partial_commit_rounds", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -80,7 +80,7 @@ int upload(pt_scene *s, int device) {
     const auto &t = s->tables;
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_exact), t.exact.size() * sizeof(pt::ExactRec) + 64));
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_mats), t.mats.size() * sizeof(pt::MatRec) + 64));
-    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 16 * sizeof(unsigned long long)));
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 24 * sizeof(unsigned long long)));
     if (!t.exact.empty()) PT_HIP_TRY(hipMemcpy(s->d_exact, t.exact.data(), t.exact.size() * sizeof(pt::ExactRec), hipMemcpyHostToDevice));
     if (!t.mats.empty()) PT_HIP_TRY(hipMemcpy(s->d_mats, t.mats.data(), t.mats.size() * sizeof(pt::MatRec), hipMemcpyHostToDevice));
     PT_HIP_TRY(hipEventCreate(&s->ev0));
@@ -366,13 +366,13 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     a.n_chunks = n_chunks;
     a.chunk_passes = chunk_passes;
     if (stats) {
-        PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 16 * sizeof(unsigned long long), stream));
+        PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 24 * sizeof(unsigned long long), stream));
         PT_HIP_TRY(hipEventRecord(scene->ev0, stream));
     }
     PT_HIP_TRY(pt::launch_integrator(a, stream));
     if (stats) {
         PT_HIP_TRY(hipEventRecord(scene->ev1, stream));
-        unsigned long long h[16];
+        unsigned long long h[24];
         PT_HIP_TRY(hipMemcpyAsync(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
         PT_HIP_TRY(hipStreamSynchronize(stream));
         float ms = -1.0f;
@@ -388,10 +388,10 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
         stats->kernel_ms = ms;
         stats->n_triangles = scene->host.n_tri();
         stats->n_chunks = static_cast<int32_t>(n_chunks);
-        stats->reserved = 0;
+        stats->partial_commit_rounds = static_cast<int32_t>(std::min<unsigned long long>(h[8], 0x7fffffffull));
 #ifdef PT_PHASE_TIMERS
         std::fprintf(stderr, "PT_PHASE_TIMERS cycles:");
-        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[8 + k]);
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[16 + k]);
         std::fprintf(stderr, "\n");
 #endif
     }

@@ -280,7 +280,7 @@ struct WaveLds {
     float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
 };
 struct WaveStats {
-    uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0;   // wave-uniform, live in SGPRs
+    uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0, w_partial = 0;   // wave-uniform, live in SGPRs
 #ifdef PT_PHASE_TIMERS
     // diagnostic build only: shader-clock cycles per phase (never compiled into the shipped library)
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -524,6 +524,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     const unsigned long long fb = __ballot(fits);
                     keep = (fb == ~0ull) ? 64u : static_cast<uint32_t>(__builtin_ctzll(~fb));
                     if (keep == 0) keep = 1;
+                    ++st.w_partial;
                 }
                 if (static_cast<uint32_t>(lane) >= keep) m8 = 0;
                 n_nodes -= keep;
@@ -870,8 +871,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         atomicAdd(&a.stats[5], static_cast<unsigned long long>(wst.w_segments));
         atomicAdd(&a.stats[6], static_cast<unsigned long long>(wst.w_node_rounds));
         atomicAdd(&a.stats[7], static_cast<unsigned long long>(wst.w_exact_iters));
+        if (wst.w_partial) atomicAdd(&a.stats[8], static_cast<unsigned long long>(wst.w_partial));
 #ifdef PT_PHASE_TIMERS
-        for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[8 + k], wst.phase[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[16 + k], wst.phase[k]);
 #endif
     }
 }

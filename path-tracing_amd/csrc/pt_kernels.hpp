@@ -22,7 +22,7 @@ struct RenderArgs {
     int32_t sky_w, sky_h;
     float *sum, *sum2;        // row band, 3 floats per pixel
     int32_t *count;
-    unsigned long long *stats;   // 8 counters or nullptr
+    unsigned long long *stats;   // 24 counters (9 used; 16.. = phase timers of diagnostic builds) or nullptr
     int32_t n_clusters, n_tri;
     int32_t width, height, row_begin, row_end;
     int32_t pass_begin, pass_count, mrr;

@@ -186,3 +186,40 @@ def test_tiny_and_empty_scenes(tmp_path):
         o = O.Scene.load(d, name)
         st, rst = _compare(g, o, 40, 40, 5, 8)
         assert st["contributing"] > 0
+
+
+def test_node_stack_overflow_paths(tmp_path):
+    """1 800 small triangles packed into a ball of radius 1: every ray through it passes nearly every sphere of the
+    tree, so a walk round produces far more children than the 96-entry node stack and the 144-entry pair queue of the
+    small-scene kernel hold -- the partial-commit and forced-commit paths run, and must not change any result."""
+    rng = np.random.default_rng(99)
+    d = str(tmp_path) + "/"
+    open(d + "m.mtl", "w").write("newmtl 0\nKe 1 1 1\nKd 1 1 1\nnewmtl 1\nNs 100\nKs 0.9 0.9 0.9\nKd 0.7 0.7 0.7\n")
+    lines = ["mtllib m.mtl"]
+    nv = 0
+    for k in range(1800):
+        c = rng.normal(size=3) * 0.35 + [0, 0, -8]
+        p, q, r = (c + rng.normal(size=3) * 0.25 for _ in range(3))
+        lines += ["v %f %f %f" % tuple(p), "v %f %f %f" % tuple(q), "v %f %f %f" % tuple(r), f"usemtl {1 if k % 9 else 0}",
+                  f"f {nv+1} {nv+2} {nv+3}"]
+        nv += 3
+    open(d + "ball.obj", "w").write("\n".join(lines) + "\n")
+    g = pt.Scene.load_obj(d, "ball.obj", device=0)
+    o = O.Scene.load(d, "ball.obj")
+    t = g.cull_tables()
+    assert list(t["kind"]) == [0] and t["n_levels"][0] == 4           # one small-triangle cluster, 1800 -> 225 -> 29 -> 4
+    # rays aimed at the ball from all around, 64 per wave all passing through the dense core
+    n = 64 * 300
+    org = (rng.normal(size=(n, 3)) * 4 + [0, 0, -8]).astype(np.float32)
+    tgt = (rng.normal(size=(n, 3)) * 0.2 + [0, 0, -8]).astype(np.float32)
+    dirs = tgt - org
+    inv = np.float32(1) / np.sqrt((dirs[:, 0] * dirs[:, 0] + dirs[:, 1] * dirs[:, 1]) + dirs[:, 2] * dirs[:, 2], dtype=np.float32)
+    dirs = (dirs * inv[:, None]).astype(np.float32)
+    gi, gt = g.trace_rays(org, dirs)
+    ri, rt, nan_seen = o.closest_hits(org, dirs)
+    assert not nan_seen.any()
+    assert np.array_equal(gi, ri) and np.array_equal(gt.view(np.uint32), rt.view(np.uint32))
+    assert (ri >= 0).mean() > 0.9
+    st, rst = _compare(g, o, 64, 48, 3, 8)                             # camera looks straight at the ball
+    assert st["partial_commit_rounds"] > 100                          # the overflow paths really ran
+    assert st["exact_tests"] > 30 * st["segments"] * 0.05              # dozens of candidates for the rays that reach it
