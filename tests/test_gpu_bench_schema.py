@@ -1,0 +1,38 @@
+"""bench.py on the GPU box: one short run, JSON contract checked field by field."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_emits_one_valid_json_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spp", "8",
+                        "--cpu-seconds", "2"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["unit"] == "Msamples/s" and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    # value is consistent with the step time: W*H*spp / ms_per_step
+    c = j["config"]
+    assert abs(j["value"] - c["width"] * c["height"] * c["spp"] / j["ms_per_step"] / 1e3) < 1e-6 * j["value"]
+    assert j["value"] > 100.0                                  # the target of BASELINE.md, with a wide margin even at 8 spp
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["kernel_ms"] > 0
+    assert rf["kernel_ms"] <= j["ms_per_step"] * 1.001         # the HIP-event kernel time fits inside the wall-clock step
+    cb = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and 0 < cb["value"] < j["value"]
