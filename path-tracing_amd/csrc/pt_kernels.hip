@@ -489,31 +489,46 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 }
                 ++st.w_node_rounds;
                 const uint32_t cnt = min(64u, n_nodes);
-                uint32_t m8 = 0, src = 0, level = 1, child0 = 0;
-                if (static_cast<uint32_t>(lane) < cnt) {
-                    const uint32_t e = lds.nodes[n_nodes - 1 - lane];
-                    src = e >> 26;
-                    level = (e >> 23) & 7u;
-                    child0 = (e & 0x7FFFFFu) * kFan;   // index of the first child within level-1
-                    Ray r;
-                    r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
-                    r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
-                    const float4 *cs = reinterpret_cast<const float4 *>(a.spheres) + off + lds.level_off[level - 1] + child0;
+                // A round with few items spreads each item's 8 children over 2, 4 or 8 lanes (wave-uniform choice).
+                uint32_t shift = cnt <= 8u ? 3u : cnt <= 16u ? 2u : cnt <= 32u ? 1u : 0u;
+                uint32_t m8, src, level, child0, keep;
+                bool leaf;
+                for (;;) {
+                    m8 = 0; src = 0; level = 1; child0 = 0;
+                    const uint32_t item = static_cast<uint32_t>(lane) >> shift, sub = static_cast<uint32_t>(lane) & ((1u << shift) - 1u);
+                    if (item < cnt) {
+                        const uint32_t e = lds.nodes[n_nodes - 1 - item];
+                        src = e >> 26;
+                        level = (e >> 23) & 7u;
+                        child0 = (e & 0x7FFFFFu) * kFan;   // index of the first child within level-1
+                        Ray r;
+                        r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                        r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                        const float4 *cs = reinterpret_cast<const float4 *>(a.spheres) + off + lds.level_off[level - 1] + child0;
+                        auto test = [&](auto per_c) {
+                            constexpr int per = decltype(per_c)::value;
+                            const uint32_t c_first = sub * per;
 #pragma unroll
-                    for (int c8 = 0; c8 < kFan; ++c8) {
-                        const float4 sp = cs[c8];
-                        m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << c8) : 0u;
+                            for (int i = 0; i < per; ++i) {
+                                const float4 sp = cs[c_first + i];
+                                m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << (c_first + i)) : 0u;
+                            }
+                        };
+                        if (shift == 0u) test(std::integral_constant<int, 8>());
+                        else if (shift == 1u) test(std::integral_constant<int, 4>());
+                        else if (shift == 2u) test(std::integral_constant<int, 2>());
+                        else test(std::integral_constant<int, 1>());
+                        const uint32_t real = lds.level_cnt[level - 1];   // padding spheres are never children
+                        const uint32_t left = real > child0 ? real - child0 : 0u;
+                        m8 &= left >= 8u ? 0xFFu : ((1u << left) - 1u);
                     }
-                    const uint32_t real = lds.level_cnt[level - 1];   // padding spheres are never children
-                    const uint32_t left = real > child0 ? real - child0 : 0u;
-                    m8 &= left >= 8u ? 0xFFu : ((1u << left) - 1u);
-                }
-                const bool leaf = level == 1;   // children are triangles
-                const uint32_t kids = __builtin_popcount(m8);
-                uint32_t keep = cnt;            // lanes [0, keep) are committed this round
-                const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = wave_sum(leaf ? 0u : kids, 4);
-                if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
-                if (n_pairs + tot_tri > kPairQueue || n_nodes - cnt + tot_node > kNodeStack) {
+                    leaf = level == 1;   // children are triangles
+                    const uint32_t kids = __builtin_popcount(m8);
+                    keep = cnt;          // items [0, keep) (from the top of the stack) are committed this round
+                    const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = wave_sum(leaf ? 0u : kids, 4);
+                    if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
+                    if (n_pairs + tot_tri <= kPairQueue && n_nodes - cnt + tot_node <= kNodeStack) break;
+                    if (shift != 0u) { shift = 0u; continue; }   // rare: redo the round one lane per item
                     // Rare: not everything fits.  Commit the longest prefix of lanes (= the top of the stack) whose
                     // children do; the other items stay where they are.  If not even the top item fits it is committed
                     // anyway: its (at most 8) children replace it, and since they are one level deeper the stack can
@@ -525,8 +540,9 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     keep = (fb == ~0ull) ? 64u : static_cast<uint32_t>(__builtin_ctzll(~fb));
                     if (keep == 0) keep = 1;
                     ++st.w_partial;
+                    if (static_cast<uint32_t>(lane) >= keep) m8 = 0;
+                    break;
                 }
-                if (static_cast<uint32_t>(lane) >= keep) m8 = 0;
                 n_nodes -= keep;
                 wave_sync();
                 // node children back on the stack
