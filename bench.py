@@ -46,10 +46,12 @@ def host_cores():
     return n
 
 
-def cpu_baseline(models, target_seconds):
+def cpu_baseline(models, target_seconds, pt, scene):
     """Times the CPU oracle (kind "port") on a bounded sample of the same workload: the central rows of the
     1920x1080 frame, -MRR 8, counter RNG; once on every core this process may use and once on 4 threads (the
-    reference's shipped THREADS_TO_RUN, CMakeLists.txt:10)."""
+    reference's shipped THREADS_TO_RUN, CMakeLists.txt:10).  The all-core sample doubles as the accuracy check of
+    BASELINE.json's metric: the GPU renders the same rows and passes and the two resolved images are compared."""
+    import numpy as np
     import oracle_lib as O
     sc = O.Scene.load(models, "Tor.obj")
     cores = min(O.lib().orc_max_threads(), host_cores())
@@ -63,17 +65,32 @@ def cpu_baseline(models, target_seconds):
         spp = max(1, min(64, int(rate * seconds / (BASE_W * rows))))
         r0 = BASE_H // 2 - rows // 2
         t = time.perf_counter()
-        _, _, _, st = O.render(sc, BASE_W, BASE_H, spp, MRR, rows=(r0, r0 + rows), threads=threads)
+        *acc, st = O.render(sc, BASE_W, BASE_H, spp, MRR, rows=(r0, r0 + rows), threads=threads)
         dt = time.perf_counter() - t
         n = BASE_W * rows * spp
-        return n / dt / 1e6, f"rows {r0}-{r0 + rows} x {spp} spp = {n} samples in {dt:.1f} s ({st['segments']} segments)"
+        return (n / dt / 1e6, f"rows {r0}-{r0 + rows} x {spp} spp = {n} samples in {dt:.1f} s ({st['segments']} segments)",
+                (r0, r0 + rows, spp, acc))
 
-    v_all, what_all = timed(cores, target_seconds * 0.65)
-    v_4, what_4 = timed(min(4, cores), target_seconds * 0.35)
+    v_all, what_all, (r0, r1, spp, cpu_acc) = timed(cores, target_seconds * 0.65)
+    v_4, what_4, _ = timed(min(4, cores), target_seconds * 0.35)
+    # accuracy: the same rows x passes through the C ABI on the GPU, then the reference's resolve on both
+    gs, gs2, gc, _ = scene.render_host(BASE_W, BASE_H, spp, MRR, rows=(r0, r1))
+    g_rgb, _ = pt.resolve_float(BASE_W, r1 - r0, gs, gs2, gc)
+    c_rgb, _ = pt.resolve_float(BASE_W, r1 - r0, *cpu_acc)
+    d = g_rgb.astype(np.float64) - c_rgb.astype(np.float64)
+    g_bgr, c_bgr = pt.quantize(g_rgb, gc), pt.quantize(c_rgb, cpu_acc[2])
+    accuracy = {"vs": "cpu_baseline sample (same rows, passes, seed)",
+                "rmse_rgb_float_image": [float(np.sqrt(np.mean(d[..., k] ** 2))) for k in range(3)],
+                "max_abs_diff_float_image": float(np.abs(d).max()),
+                "bmp_bytes_differing": int(np.count_nonzero(g_bgr != c_bgr)),
+                "accumulators_bit_identical": bool(np.array_equal(gs.view(np.uint32), cpu_acc[0].view(np.uint32)) and
+                                                   np.array_equal(gs2.view(np.uint32), cpu_acc[1].view(np.uint32)) and
+                                                   np.array_equal(gc, cpu_acc[2])),
+                "tolerance": "bit-exact (0); tests/test_gpu_parity.py holds the same bar"}
     return {"value": v_all, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "value_4_threads": v_4,
             "sample": f"Tor.obj 1920x1080 frame, MRR {MRR}, oracle/pt_oracle.c with OpenMP over rows; {cores} threads: {what_all}; "
-                      f"4 threads: {what_4}"}
+                      f"4 threads: {what_4}"}, accuracy
 
 
 def main():
@@ -173,12 +190,13 @@ def main():
         n_chunks = max(1, stats[0].get("n_chunks", 1))
         algo_bytes = npx * 28 * 2 * n_chunks + n_tri * 112
         traffic = valu_util = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")   # written by tools/summarize_pmc.py from rocprofv3 --pmc passes
-        if world == 1 and os.path.exists(pmc):
+        # PMC summaries written by tools/summarize_pmc.py from rocprofv3 --pmc passes of this same command line
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json"))) if world == 1 else []:
             j = json.load(open(pmc))
             if j.get("spp") == args.spp and j.get("width") == W and j.get("height") == H:
-                traffic = j.get("hbm_bytes_per_launch")
-                valu_util = j.get("valu_issue_utilisation")
+                traffic = j.get("hbm_bytes_per_launch", traffic)
+                valu_util = j.get("valu_issue_utilisation", valu_util)
         out = {
             "metric": "Msamples/sec (WxHxspp/wall) on Tor.obj 1080p",
             "value": samples_per_step * k / elapsed / 1e6,
@@ -205,7 +223,7 @@ def main():
                                  "frac": (algo_bytes / (kms * 1e-3) / 1e9) / PEAK_HBM_GBS if kms > 0 else 0.0}},
         }
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(models, args.cpu_seconds)
+            out["cpu_baseline"], out["accuracy"] = cpu_baseline(models, args.cpu_seconds, pt, scene)
         if args.write_bmp:
             parts = [t.cpu().numpy() for t in gathered[0]] if world > 1 else [band.cpu().numpy()]
             s, s2, c = bands.assemble(parts, W, H, world)

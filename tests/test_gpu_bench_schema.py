@@ -36,3 +36,7 @@ def test_bench_emits_one_valid_json_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and 0 < cb["value"] < j["value"]
+    # the accuracy half of BASELINE.json's metric: GPU vs the CPU path on the sample both rendered
+    ac = j["accuracy"]
+    assert ac["accumulators_bit_identical"] is True and ac["bmp_bytes_differing"] == 0
+    assert ac["rmse_rgb_float_image"] == [0.0, 0.0, 0.0] and ac["max_abs_diff_float_image"] == 0.0

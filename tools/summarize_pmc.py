@@ -37,16 +37,17 @@ def main():
     ap.add_argument("--fetch-scale", type=float, default=1.0,
                     help="FETCH_SIZE calibration for this kernel's access pattern (the guide's x2 holds for wide streaming reads; "
                          "this kernel's 4-byte strided accumulator loads count 1:1, see the note in the output)")
+    ap.add_argument("--out-dir", default=os.path.join(ROOT, "profiles"))
     a = ap.parse_args()
-    out_dir = os.path.join(ROOT, "profiles")
+    out_dir = a.out_dir
     os.makedirs(out_dir, exist_ok=True)
     if a.kernel_trace:
-        f = newest(glob.glob(os.path.join(a.kernel_trace, "*", "*_kernel_stats.csv")))
+        f = newest(glob.glob(os.path.join(a.kernel_trace, "**", "*kernel_stats.csv"), recursive=True))
         shutil.copy(f, os.path.join(out_dir, f"{a.tag}_kernel_stats.csv"))
     counters = collections.defaultdict(float)
     for d in a.pmc:
         # gpurun merges every call's output into the same local directory: only the newest run counts
-        for f in [newest(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")))]:
+        for f in [newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))]:
             for r in csv.DictReader(open(f)):
                 if "integrate_kernel" in r["Kernel_Name"]:
                     counters[r["Counter_Name"]] += float(r["Counter_Value"]) / a.launches_per_pass
