@@ -25,6 +25,9 @@
  * A render call ADDS passes [pass_begin, pass_begin+pass_count) to the buffers it is given, so a frame can be
  * rendered in slices (previews, time limits: main.cpp:111-114,141-158) and an image in row bands (multi-GPU).
  * There is no CPU fallback: without a usable HIP device the render entry points fail with PT_ERR_NO_DEVICE.
+ * Threads and streams: a pt_scene may be rendered from several host threads and on several streams; the library
+ * orders the launches of ONE scene on the device (they share its scheduler state), launches of different scenes are
+ * independent.  pt_scene_set_skybox_bmp and pt_scene_destroy must not race with a render of the same scene.
  */
 #ifndef PT_HIP_H
 #define PT_HIP_H

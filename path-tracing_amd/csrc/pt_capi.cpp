@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -45,6 +46,12 @@ struct pt_scene {
     int sky_w = 0, sky_h = 0;
     uint8_t *d_sky = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // The scheduler words, the statistics block and the timing events are per scene: launches of one scene are
+    // enqueued under launch_mutex and ordered on the device by ev_done, whatever streams the callers use.
+    std::mutex launch_mutex;
+    hipEvent_t ev_done = nullptr;
+    bool has_prev = false;
+    hipStream_t prev_stream = nullptr;
 };
 
 namespace {
@@ -85,6 +92,7 @@ int upload(pt_scene *s, int device) {
     if (!t.mats.empty()) PT_HIP_TRY(hipMemcpy(s->d_mats, t.mats.data(), t.mats.size() * sizeof(pt::MatRec), hipMemcpyHostToDevice));
     PT_HIP_TRY(hipEventCreate(&s->ev0));
     PT_HIP_TRY(hipEventCreate(&s->ev1));
+    PT_HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     return PT_OK;
 }
 
@@ -121,25 +129,22 @@ int ensure_cull(pt_scene *s, float eps) {
     return PT_OK;
 }
 
-int finish_scene(pt_scene *s, int device, pt_scene **out) {
-    if (s->host.n_tri() >= (1 << 24)) {   // work items carry the triangle index in 24 bits
-        delete s;
+struct SceneDeleter {
+    void operator()(pt_scene *s) const { pt_scene_destroy(s); }
+};
+using ScenePtr = std::unique_ptr<pt_scene, SceneDeleter>;   // frees host and device side on every early return / exception
+
+int finish_scene(ScenePtr s, int device, pt_scene **out) {
+    if (s->host.n_tri() >= (1 << 24))   // work items carry the triangle index in 24 bits
         return fail(PT_ERR_INVALID_ARGUMENT, "more than 16 777 215 triangles");
-    }
     for (int m : s->host.tri_mat)
-        if (m < 0 || m >= s->host.n_mat()) {
-            delete s;
-            return fail(PT_ERR_INVALID_ARGUMENT, "triangle refers to material " + std::to_string(m));
-        }
+        if (m < 0 || m >= s->host.n_mat()) return fail(PT_ERR_INVALID_ARGUMENT, "triangle refers to material " + std::to_string(m));
     pt::build_device_tables(s->host, s->tables);
     if (device >= 0) {
-        const int rc = upload(s, device);
-        if (rc != PT_OK) {
-            pt_scene_destroy(s);
-            return rc;
-        }
+        const int rc = upload(s.get(), device);
+        if (rc != PT_OK) return rc;
     }
-    *out = s;
+    *out = s.release();
     return PT_OK;
 }
 
@@ -161,6 +166,20 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.n_tri = scene->host.n_tri();
     a.eps = eps;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.m0_quad = cc.m0_quad; a.t_guard = cc.t_guard;
+}
+
+// No exception may cross the C boundary: allocation failures and anything else become status codes.
+template <class F>
+int guarded(F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(PT_ERR_OUT_OF_MEMORY, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(PT_ERR_INVALID_ARGUMENT, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(PT_ERR_INVALID_ARGUMENT, "internal error");
+    }
 }
 
 int check_params(const pt_scene *scene, const pt_render_params *p) {
@@ -189,35 +208,30 @@ int pt_device_count(void) {
 
 const char *pt_last_error(void) { return g_error.c_str(); }
 
-int pt_scene_load_obj(const char *model_dir, const char *model_name, int device, pt_scene **out) {
+static int scene_load_obj_impl(const char *model_dir, const char *model_name, int device, pt_scene **out) {
     if (!model_dir || !model_name || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    pt_scene *s = new (std::nothrow) pt_scene;
-    if (!s) return fail(PT_ERR_OUT_OF_MEMORY, "out of host memory");
+    ScenePtr s(new pt_scene);
     std::string err;
     bool io = false;
-    if (!pt::load_obj(model_dir, model_name, s->host, err, io)) {
-        delete s;
-        return fail(io ? PT_ERR_IO : PT_ERR_PARSE, err);
-    }
-    return finish_scene(s, device, out);
+    if (!pt::load_obj(model_dir, model_name, s->host, err, io)) return fail(io ? PT_ERR_IO : PT_ERR_PARSE, err);
+    return finish_scene(std::move(s), device, out);
 }
 
-int pt_scene_create(const float *triangles, const int32_t *triangle_material, int32_t n_triangles, const float *materials,
+static int scene_create_impl(const float *triangles, const int32_t *triangle_material, int32_t n_triangles, const float *materials,
                     int32_t n_materials, int device, pt_scene **out) {
     if (!out || n_triangles < 0 || n_materials < 0 || (n_triangles > 0 && (!triangles || !triangle_material)) ||
         (n_materials > 0 && !materials))
         return fail(PT_ERR_INVALID_ARGUMENT, "null table or negative count");
     *out = nullptr;
-    pt_scene *s = new (std::nothrow) pt_scene;
-    if (!s) return fail(PT_ERR_OUT_OF_MEMORY, "out of host memory");
+    ScenePtr s(new pt_scene);
     s->host.tri.assign(triangles, triangles + static_cast<size_t>(n_triangles) * PT_TRIANGLE_FLOATS);
     s->host.tri_mat.assign(triangle_material, triangle_material + n_triangles);
     s->host.mat.assign(materials, materials + static_cast<size_t>(n_materials) * PT_MATERIAL_FLOATS);
-    return finish_scene(s, device, out);
+    return finish_scene(std::move(s), device, out);
 }
 
-int pt_scene_set_skybox_bmp(pt_scene *scene, const char *path) {
+static int scene_set_skybox_bmp_impl(pt_scene *scene, const char *path) {
     if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
     std::vector<uint8_t> texels;
     int w = 0, h = 0;
@@ -311,11 +325,12 @@ void pt_scene_destroy(pt_scene *s) {
         if (s->d_sched) (void)hipFree(s->d_sched);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
+        if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     }
     delete s;
 }
 
-int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, float *d_sum2, int32_t *d_count,
+static int render_device_impl(pt_scene *scene, const pt_render_params *p, float *d_sum, float *d_sum2, int32_t *d_count,
                      void *hip_stream, pt_render_stats *stats) {
     const int rc = check_params(scene, p);
     if (rc != PT_OK) return rc;
@@ -352,6 +367,8 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     const int32_t chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
     n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
     if (static_cast<unsigned long long>(n_tiles) * n_chunks > 0x7fffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "too many work items");
+    std::lock_guard<std::mutex> launch_lock(scene->launch_mutex);
+    if (scene->has_prev && scene->prev_stream != stream) PT_HIP_TRY(hipStreamWaitEvent(stream, scene->ev_done, 0));
     if (scene->sched_words < 1 + static_cast<size_t>(n_tiles)) {
         PT_HIP_TRY(hipStreamSynchronize(stream));
         if (scene->d_sched) (void)hipFree(scene->d_sched);
@@ -370,6 +387,9 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
         PT_HIP_TRY(hipEventRecord(scene->ev0, stream));
     }
     PT_HIP_TRY(pt::launch_integrator(a, stream));
+    PT_HIP_TRY(hipEventRecord(scene->ev_done, stream));
+    scene->has_prev = true;
+    scene->prev_stream = stream;
     if (stats) {
         PT_HIP_TRY(hipEventRecord(scene->ev1, stream));
         unsigned long long h[24];
@@ -398,7 +418,7 @@ int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, f
     return PT_OK;
 }
 
-int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps,
+static int trace_rays_host_impl(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps,
                        int32_t *hit_index, float *hit_t) {
     if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
     if (scene->device < 0) return fail(PT_ERR_NO_DEVICE, "scene was created without a device (device < 0)");
@@ -432,7 +452,7 @@ int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, co
     return result;
 }
 
-int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float *sum2, int32_t *count,
+static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *sum, float *sum2, int32_t *count,
                    pt_render_stats *stats) {
     const int rc = check_params(scene, p);
     if (rc != PT_OK) return rc;
@@ -450,7 +470,7 @@ int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float
     if (e == hipSuccess) e = hipMemcpy(d_sum2, sum2, n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_count, count, n * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) result = hip_fail(e, "staging the accumulators");
-    if (result == PT_OK) result = pt_render_device(scene, p, d_sum, d_sum2, d_count, nullptr, stats);
+    if (result == PT_OK) result = render_device_impl(scene, p, d_sum, d_sum2, d_count, nullptr, stats);
     if (result == PT_OK) {
         e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(sum, d_sum, n * 12, hipMemcpyDeviceToHost);
@@ -464,7 +484,7 @@ int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float
     return result;
 }
 
-int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary,
+static int scene_cull_tables_impl(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary,
                          float *constants) {
     if (!scene || !counts) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     pt::CullTables t;
@@ -561,7 +581,7 @@ int pt_resolve_float(int32_t width, int32_t height, const float *sum, const floa
     return PT_OK;
 }
 
-int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median) {
+static int post_filter_host_impl(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median) {
     if (width <= 0 || height <= 0 || !rgb) return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
     if (gauss < 0 || median < 0) return fail(PT_ERR_INVALID_ARGUMENT, "negative filter size");
     if (median * median / 2 > pt::kMedianMaxRank) return fail(PT_ERR_INVALID_ARGUMENT, "-MEDIAN window larger than 11 is not supported");
@@ -645,6 +665,40 @@ int pt_write_bmp(const char *path, int32_t width, int32_t height, const uint8_t 
     }
     ok = (std::fclose(f) == 0) && ok;
     return ok ? PT_OK : fail(PT_ERR_IO, std::string("short write to ") + path);
+}
+
+// ---- the guarded entry points (definitions above are the bodies) ----
+
+int pt_scene_load_obj(const char *model_dir, const char *model_name, int device, pt_scene **out) {
+    return guarded([&] { return scene_load_obj_impl(model_dir, model_name, device, out); });
+}
+
+int pt_scene_create(const float *triangles, const int32_t *triangle_material, int32_t n_triangles, const float *materials, int32_t n_materials, int device, pt_scene **out) {
+    return guarded([&] { return scene_create_impl(triangles, triangle_material, n_triangles, materials, n_materials, device, out); });
+}
+
+int pt_scene_set_skybox_bmp(pt_scene *scene, const char *path) {
+    return guarded([&] { return scene_set_skybox_bmp_impl(scene, path); });
+}
+
+int pt_render_device(pt_scene *scene, const pt_render_params *p, float *d_sum, float *d_sum2, int32_t *d_count, void *hip_stream, pt_render_stats *stats) {
+    return guarded([&] { return render_device_impl(scene, p, d_sum, d_sum2, d_count, hip_stream, stats); });
+}
+
+int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps, int32_t *hit_index, float *hit_t) {
+    return guarded([&] { return trace_rays_host_impl(scene, n_rays, origins, directions, eps, hit_index, hit_t); });
+}
+
+int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float *sum2, int32_t *count, pt_render_stats *stats) {
+    return guarded([&] { return render_host_impl(scene, p, sum, sum2, count, stats); });
+}
+
+int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary, float *constants) {
+    return guarded([&] { return scene_cull_tables_impl(scene, eps, counts, clusters, spheres, bary, constants); });
+}
+
+int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median) {
+    return guarded([&] { return post_filter_host_impl(device, width, height, rgb, gauss, median); });
 }
 
 }  // extern "C"

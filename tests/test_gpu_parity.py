@@ -223,3 +223,27 @@ def test_node_stack_overflow_paths(tmp_path):
     st, rst = _compare(g, o, 64, 48, 3, 8)                             # camera looks straight at the ball
     assert st["partial_commit_rounds"] > 100                          # the overflow paths really ran
     assert st["exact_tests"] > 30 * st["segments"] * 0.05              # dozens of candidates for the rays that reach it
+
+
+def test_device_pointer_path_on_two_streams(gpu_scene):
+    """pt_render_device with caller-owned device buffers (the bench / integration path), launched back to back on two
+    different streams without a host synchronisation in between: a scene's launches share its scheduler words, so the
+    library has to order them on the device; both frames must equal the pt_render_host frame bit for bit."""
+    import torch
+    W, H, spp, mrr = 320, 200, 12, 8
+    n = W * H
+    dev = torch.device("cuda", 0)
+    p = pt.RenderParams(W, H, 0, H, 0, spp, mrr, 1e-4, -1.0, 42)
+    bufs = [torch.zeros(7 * n, dtype=torch.float32, device=dev) for _ in range(3)]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize(dev)
+    for k in range(3):   # third launch: back on the first stream
+        b = bufs[k]
+        gpu_scene.render_device(p, b.data_ptr(), b.data_ptr() + 12 * n, b.data_ptr() + 24 * n,
+                                stream=streams[k % 2].cuda_stream)
+    torch.cuda.synchronize(dev)
+    s, s2, c, _ = gpu_scene.render_host(W, H, spp, mrr)
+    for b in bufs:
+        h = b.cpu().numpy()
+        assert _same(h[:3 * n], s.ravel()) and _same(h[3 * n:6 * n], s2.ravel())
+        assert np.array_equal(h[6 * n:].view(np.int32), c)
