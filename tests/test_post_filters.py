@@ -41,7 +41,8 @@ def test_filter_argument_checks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gauss,median", [(1, 0), (3, 0), (0, 1), (0, 3), (0, 11)])
+# -GAUSS 1..9 run the LDS-tiled kernel, 10 the global-memory one; -MEDIAN 1..3 the register kernels, 4 and 11 the generic one
+@pytest.mark.parametrize("gauss,median", [(1, 0), (3, 0), (9, 0), (10, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 11)])
 def test_gpu_filters_bit_exact(oracle_scene, gauss, median):
     W, H = 44, 31
     s, s2, c = _frame(oracle_scene)
