@@ -222,6 +222,16 @@ def main():
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": (algo_bytes / (kms * 1e-3) / 1e9) / PEAK_HBM_GBS if kms > 0 else 0.0}},
         }
+        if world == 1:
+            # the host-buffer boundary (pt_render_host): same frame, accumulators staged over PCIe both ways; not `value`
+            import numpy as np
+            acc = (np.zeros((npx, 3), np.float32), np.zeros((npx, 3), np.float32), np.zeros(npx, np.int32))
+            scene.render_host(W, H, args.spp, MRR, accum=acc, want_stats=False)      # warm-up
+            th = time.perf_counter()
+            scene.render_host(W, H, args.spp, MRR, accum=acc, want_stats=False)
+            th = time.perf_counter() - th
+            out["pcie_inclusive"] = {"value": samples_per_step / th / 1e6, "unit": "Msamples/s", "ms_per_step": th * 1e3,
+                                     "what": "pt_render_host: 116 MB of accumulators host->device and back (pageable memory) around the same launch"}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["accuracy"] = cpu_baseline(models, args.cpu_seconds, pt, scene)
         if args.write_bmp:

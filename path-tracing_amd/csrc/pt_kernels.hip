@@ -37,7 +37,12 @@ constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per w
 // leaves room for 6+ waves per SIMD; scenes with thousands of triangles get deep queues (fuller rounds) and pay with
 // occupancy, which matters less there.
 struct SmallQueues { static constexpr int kNodeStack = 96, kPairQueue = 144, kFiltered = 1; };
-struct BigQueues { static constexpr int kNodeStack = 832, kPairQueue = 512, kFiltered = 128; };
+#ifndef PT_BIG_NODES
+#define PT_BIG_NODES 832
+#define PT_BIG_PAIRS 512
+#define PT_BIG_FILTERED 128
+#endif
+struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -270,6 +275,10 @@ template <class Q>
 struct WaveLds {
     static constexpr int kNodeStack = Q::kNodeStack, kPairQueue = Q::kPairQueue;
     static constexpr bool kPrefilter = Q::kFiltered > 1;   // big scenes: thin the pairs with the barycentric test first
+    // The code that fills the queues relies on these minima (see push_pairs_any, drain_pairs and the tree walk):
+    static_assert(Q::kPairQueue >= 128, "push_pairs_any publishes slices of up to 128 pairs");
+    static_assert(!kPrefilter || Q::kFiltered >= 128, "the pre-filter appends up to 64 survivors to up to 63 waiting ones");
+    static_assert(Q::kNodeStack >= 64, "a round pops up to 64 nodes");
     uint32_t filtered[Q::kFiltered];   // pairs that survived the pre-filter, waiting for a full exact round
     unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
     float ray[6][64];              // this segment's rays, readable by every lane
