@@ -38,8 +38,8 @@ constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per w
 // occupancy, which matters less there.
 struct SmallQueues { static constexpr int kNodeStack = 96, kPairQueue = 144, kFiltered = 1; };
 #ifndef PT_BIG_NODES
-#define PT_BIG_NODES 832
-#define PT_BIG_PAIRS 512
+#define PT_BIG_NODES 384      // measured on the 16 398- and 49 934-triangle scenes: 832 / 512 (4 waves per SIMD) is 4 % slower,
+#define PT_BIG_PAIRS 256      // 256 / 160 (6 waves per SIMD) 7 % slower than this (5 waves per SIMD)
 #define PT_BIG_FILTERED 128
 #endif
 struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };

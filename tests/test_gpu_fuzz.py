@@ -2,6 +2,7 @@
 triangles (ties must go to the lowest index, scene.cpp:116-120 with the strict '<' of triangles.h:51), triangles with
 and without vertex normals, all material kinds; closest hits for explicit rays and small frames, bit for bit."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -72,7 +73,16 @@ def _norm(d):
     return (d * inv[:, None]).astype(np.float32)
 
 
-@pytest.mark.parametrize("seed,n_small,n_large,n_dup", [(1, 300, 6, 20), (2, 40, 30, 10), (3, 3000, 10, 40)])
+def _configs():
+    base = [(1, 300, 6, 20), (2, 40, 30, 10), (3, 3000, 10, 40)]
+    extra = int(os.environ.get("PT_FUZZ_EXTRA", "0"))      # soak: PT_FUZZ_EXTRA=20 python -m pytest tests/test_gpu_fuzz.py -m gpu
+    rng = np.random.default_rng(4242)
+    for k in range(extra):
+        base.append((100 + k, int(rng.choice([10, 100, 700, 2500, 6000])), int(rng.integers(0, 40)), int(rng.integers(1, 60))))
+    return base
+
+
+@pytest.mark.parametrize("seed,n_small,n_large,n_dup", _configs())
 def test_random_scene(tmp_path, seed, n_small, n_large, n_dup):
     d = str(tmp_path) + "/"
     n = _random_scene(d, seed, n_small, n_large, n_dup)
