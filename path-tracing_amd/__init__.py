@@ -62,11 +62,36 @@ def build(force=False):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheels bundle their own libamdhip64.so.7.  A process that ends up with two HIP runtimes (the
+    system one pulled in by libpt_hip.so, then torch's) loses the GPU in whichever initialises second -- torch reported
+    "No HIP GPUs are available" when it was imported after this library.  If torch is installed, load its copy first
+    (located without importing torch): the dynamic linker then resolves libpt_hip.so's libamdhip64.so.7 to it, as
+    it already does when torch is imported first, and the order of imports stops mattering."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("PT_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: run `make -C {CSRC_DIR}` (there is no CPU fallback)")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
         L.pt_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
