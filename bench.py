@@ -145,9 +145,22 @@ def main():
     params = pt.RenderParams(W, H, r0, r1, 0, args.spp, MRR, 1e-4, -1.0, 42)
     stream = torch.cuda.current_stream(dev)
 
+    # Timed steps launch without pt_render_stats (the library then runs the kernel instantiation without its nine
+    # diagnostic counters, as a caller that only wants the frame does) and are bracketed by HIP events on the launch
+    # stream; the counters of the same deterministic frame (segments, chunks per tile) come from an untimed launch.
+    events = []
+
     def step(timed):
         band.zero_()
-        st = scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=True)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=False)
+            e1.record(stream)
+            events.append((e0, e1))
+            st = None
+        else:
+            st = scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=True)
         if world > 1:   # the frame's one collective (RCCL; gloo on host copies when rehearsing)
             gathered[0] = bands.gather_bands(band.cpu() if args.rehearse_on_one_gpu else band, W, H, dist, rank, world)
         return st
@@ -157,13 +170,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step(False)
+    frame_stats = None
+    for _ in range(max(args.warmup, 1)):   # at least one untimed launch: it supplies the frame's counters
+        frame_stats = step(False)
     fence()
     t0 = time.perf_counter()
-    stats = [step(True) for _ in range(args.steps)]
+    for _ in range(args.steps):
+        step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    stats = [dict(frame_stats, kernel_ms=e0.elapsed_time(e1)) for e0, e1 in events] or [dict(frame_stats, kernel_ms=0.0)]
     if world > 1:
         rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -215,7 +231,7 @@ def main():
             # most ray-triangle pairs, so this can exceed the ALU peak -- valu_issue_utilisation_pmc is the hardware view
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "pt::integrate_kernel<false,false>", "kernel_ms": kms,
+                         "kernel": "pt::integrate_kernel<false,false,false>", "kernel_ms": kms,
                          "valu_issue_utilisation_pmc": valu_util, "segments_per_launch": seg,
                          "flop_per_test": FLOP_PER_TEST,
                          "hbm": {"algorithmic_bytes": algo_bytes, "chunks_per_tile": n_chunks, "achieved": algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,

@@ -296,6 +296,17 @@ struct WaveStats {
     unsigned long long last = 0;
 #endif
 };
+// Launches that do not ask for pt_render_stats run an instantiation without any of the counters (they cost ~3 %:
+// nine more wave-uniform values alive across the whole kernel push the scalar register file into spilling).
+struct Ignored {
+    __host__ __device__ Ignored() {}
+    __host__ __device__ Ignored(uint32_t) {}
+    template <class T> __host__ __device__ Ignored &operator+=(T) { return *this; }
+    __host__ __device__ Ignored &operator++() { return *this; }
+};
+struct NoStats {
+    Ignored n_exact, w_segments, w_node_rounds, w_exact_iters, w_partial;
+};
 #ifdef PT_PHASE_TIMERS
 #define PT_STAMP(st, idx)                                              \
     do {                                                               \
@@ -325,9 +336,9 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-template <class Lds>
+template <class Lds, class Stats>
 __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray &q, bool valid, int lane,
-                                            float eps, float &best, int &hit, WaveStats &st) {
+                                            float eps, float &best, int &hit, Stats &st) {
     constexpr uint32_t kNodeStack = Lds::kNodeStack, kPairQueue = Lds::kPairQueue;
     ++st.w_segments;
     PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
@@ -626,7 +637,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 // SKY = the scene has a skybox (scene.cpp:126-154).  A separate instantiation: the lookup's double arithmetic raises
 // the register peak, and the no-skybox kernel (every BASELINE configuration) should not pay for it.
 // BIG = deep work queues for scenes with thousands of triangles (see SmallQueues / BigQueues).
-template <bool SKY, bool BIG>
+// STATS = the caller asked for pt_render_stats.
+template <bool SKY, bool BIG, bool STATS>
 __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;   // one wave per workgroup: all wave-private
 
@@ -682,8 +694,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
     if (in_image) lowvar = low_variance(lds.acc[0][lane], lds.acc[1][lane], lds.acc[2][lane], lds.acc[3][lane], lds.acc[4][lane],
                                         lds.acc[5][lane], __float_as_int(lds.acc[6][lane]));
     // statistics are wave-level (uniform) counts: they live in SGPRs
-    uint32_t n_traced = 0, n_segments = 0, n_contrib = 0, n_miss = 0;
-    WaveStats wst;
+    using Count = std::conditional_t<STATS, uint32_t, Ignored>;
+    Count n_traced = 0, n_segments = 0, n_contrib = 0, n_miss = 0;
+    std::conditional_t<STATS, WaveStats, NoStats> wst;
 #ifdef PT_PHASE_TIMERS
     wst.last = __builtin_amdgcn_s_memtime();
 #endif
@@ -720,19 +733,19 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
             q.ox = q.oy = q.oz = 0.0f; q.dx = q.dy = 0.0f; q.dz = 1.0f;
         }
 
-        n_traced += __builtin_popcountll(__ballot(!skip));
+        if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(!skip));
 
         for (;;) {
             const bool valid = depth < mrr && (tr != 0.0f || tg != 0.0f || tb != 0.0f);   // Ray::IsValid, ray.h:52-54
             if (!__any(valid)) break;
-            n_segments += __builtin_popcountll(__ballot(valid));
+            if constexpr (STATS) n_segments += __builtin_popcountll(__ballot(valid));
 
             float best;
             int hit;
             closest_hit(a, lds, q, valid, lane, eps, best, hit, wst);
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
-            n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
+            if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
             bool contributed = false;
             if (valid) {
                 if (hit < 0) {
@@ -834,7 +847,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
                     }
                 }
             }
-            n_contrib += __builtin_popcountll(__ballot(contributed));
+            if constexpr (STATS) n_contrib += __builtin_popcountll(__ballot(contributed));
             PT_STAMP(wst, 7);   // shading
         }
     }
@@ -887,7 +900,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler (guide, G16)
         if (lane == 0) __hip_atomic_store(&a.sched[1 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (a.stats && lane == 0) {
+    if constexpr (STATS) if (a.stats && lane == 0) {
         atomicAdd(&a.stats[0], static_cast<unsigned long long>(n_traced));
         atomicAdd(&a.stats[1], static_cast<unsigned long long>(n_segments));
         atomicAdd(&a.stats[2], static_cast<unsigned long long>(n_contrib));
@@ -941,10 +954,23 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     if (rows <= 0 || args.width <= 0) return hipSuccess;
     const unsigned grid = args.n_tiles * args.n_chunks;
     const bool big = args.n_tri > kBigSceneTriangles;
-    if (args.sky && big) hipLaunchKernelGGL((integrate_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, args);
-    else if (args.sky) hipLaunchKernelGGL((integrate_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, args);
-    else if (big) hipLaunchKernelGGL((integrate_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, args);
-    else hipLaunchKernelGGL((integrate_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, args);
+#ifdef PT_PHASE_TIMERS
+    const bool stats = true;
+#else
+    const bool stats = args.stats != nullptr;
+#endif
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args); };
+    if (stats) {
+        if (args.sky && big) go(integrate_kernel<true, true, true>);
+        else if (args.sky) go(integrate_kernel<true, false, true>);
+        else if (big) go(integrate_kernel<false, true, true>);
+        else go(integrate_kernel<false, false, true>);
+    } else {
+        if (args.sky && big) go(integrate_kernel<true, true, false>);
+        else if (args.sky) go(integrate_kernel<true, false, false>);
+        else if (big) go(integrate_kernel<false, true, false>);
+        else go(integrate_kernel<false, false, false>);
+    }
     return hipGetLastError();
 }
 

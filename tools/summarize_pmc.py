@@ -32,7 +32,6 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--launches-per-pass", type=int, default=1)
     ap.add_argument("--chunks", type=int, default=1, help="pass-range chunks per tile of the profiled launch (pt_render_stats.n_chunks)")
     ap.add_argument("--fetch-scale", type=float, default=1.0,
                     help="FETCH_SIZE calibration for this kernel's access pattern (the guide's x2 holds for wide streaming reads; "
@@ -48,9 +47,15 @@ def main():
     for d in a.pmc:
         # gpurun merges every call's output into the same local directory: only the newest run counts
         for f in [newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))]:
-            for r in csv.DictReader(open(f)):
-                if "integrate_kernel" in r["Kernel_Name"]:
-                    counters[r["Counter_Name"]] += float(r["Counter_Value"]) / a.launches_per_pass
+            rows = [r for r in csv.DictReader(open(f)) if "integrate_kernel" in r["Kernel_Name"]]
+            # bench.py's timed launches run the instantiation without statistics (third template argument false);
+            # its untimed launch with statistics is not what the bench line reports
+            timed = [r for r in rows if r["Kernel_Name"].replace(" ", "").endswith("false>(pt::RenderArgs)")]
+            use = timed or rows
+            # every such launch renders the same frame (timed steps, the PCIe-inclusive leg): report the mean per launch
+            launches = len({r["Dispatch_Id"] for r in use}) or 1
+            for r in use:
+                counters[r["Counter_Name"]] += float(r["Counter_Value"]) / launches
     summary = {"tag": a.tag, "kernel": "pt::integrate_kernel", "width": a.width, "height": a.height, "spp": a.spp, "mrr": 8,
                "counters_per_launch": dict(counters)}
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
@@ -65,8 +70,7 @@ def main():
                            "streaming reads and other widths must be calibrated on a known byte count: this kernel's reads are the "
                            "accumulators (28 B/pixel per chunk, 4-byte strided loads); FETCH_SIZE counts 0.76-1.0 of them (1.00 measured with "
                            "4 chunks, 0.76 with 5: a chunk's re-read can hit the L2 that wrote the tile back), so no x2 is applied.  WRITE_SIZE = the accumulator write-backs (28 B/pixel per chunk, 16-byte stores) plus one 64-byte "
-                           "request for each of the ~10 atomics / flag stores a work item issues (ticket, hand-off flag, 8 statistics "
-                           "counters).")
+                           "request for each atomic / flag store a work item issues (ticket, hand-off flag; 8 more with statistics).")
     if "SQ_INSTS_VALU" in counters and "GRBM_GUI_ACTIVE" in counters:
         cyc = counters["GRBM_GUI_ACTIVE"] / 8.0
         summary["valu_issue_utilisation"] = counters["SQ_INSTS_VALU"] * 2.0 / (cyc * 1024.0)
