@@ -15,10 +15,13 @@ dev = torch.device("cuda", 0)
 buf = torch.zeros(7 * n, dtype=torch.float32, device=dev)
 p = pt.RenderParams(W, H, 0, H, 0, a.spp, 8, 1e-4, 0.001, 42)
 digests = set()
+last = None
 for f in range(a.frames):
     buf.zero_()
     st = sc.render_device(p, buf.data_ptr(), buf.data_ptr() + 12 * n, buf.data_ptr() + 24 * n,
-                          stream=torch.cuda.current_stream(dev).cuda_stream, want_stats=True)
+                          stream=torch.cuda.current_stream(dev).cuda_stream, want_stats=(f % 2 == 0))   # both instantiations
+    st = st or last
+    last = st
     digests.add(hashlib.sha256(buf.cpu().numpy().tobytes()).hexdigest())
 print(f"{a.frames} frames of {W}x{H}x{a.spp} (adaptive on): {len(digests)} distinct digest(s); last kernel {st['kernel_ms']:.2f} ms")
 sys.exit(0 if len(digests) == 1 else 1)
