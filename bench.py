@@ -248,6 +248,21 @@ def main():
             th = time.perf_counter() - th
             out["pcie_inclusive"] = {"value": samples_per_step / th / 1e6, "unit": "Msamples/s", "ms_per_step": th * 1e3,
                                      "what": "pt_render_host: 116 MB of accumulators host->device and back (pageable memory) around the same launch"}
+        exe = os.path.join(ROOT, "path-tracing_amd", "bin", "pt_render")
+        if world == 1 and os.path.exists(exe):
+            # end to end: the stand-alone front end from process start to the BMP on disk -- HIP start-up,
+            # OBJ/MTL load, table build, render through pt_render_host, resolve (powf), BMP write.  A child process.
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                cmd = [exe, "--W", str(W), "--H", str(H), "-RPP", str(args.spp), "-MRR", str(MRR), "-ERR", "-1", "-UPDATE", "0",
+                       "-QUIET", "1", "-SEED", "42", "-MODEL_PATH", models, "-OUT", os.path.join(td, "frame.bmp")]
+                te = time.perf_counter()
+                r = subprocess.run(cmd, cwd=td, capture_output=True, text=True)
+                te = time.perf_counter() - te
+                ok = r.returncode == 0 and os.path.getsize(os.path.join(td, "frame.bmp")) == 54 + W * H * 3
+            out["end_to_end"] = {"value": samples_per_step / te / 1e6 if ok else None, "unit": "Msamples/s", "seconds": te,
+                                 "what": "pt_render (C++ front end) as a child process: process start -> BMP on disk"}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["accuracy"] = cpu_baseline(models, args.cpu_seconds, pt, scene)
         if args.write_bmp:

@@ -40,3 +40,6 @@ def test_bench_emits_one_valid_json_line():
     ac = j["accuracy"]
     assert ac["accumulators_bit_identical"] is True and ac["bmp_bytes_differing"] == 0
     assert ac["rmse_rgb_float_image"] == [0.0, 0.0, 0.0] and ac["max_abs_diff_float_image"] == 0.0
+    # the other two rates of SURVEY 8(d): PCIe-inclusive entry point and process start -> BMP
+    assert 0 < j["pcie_inclusive"]["value"] <= j["value"] * 1.05
+    assert j["end_to_end"]["value"] is not None and 0 < j["end_to_end"]["value"] < j["value"]
