@@ -443,6 +443,27 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         }
     };
 
+    // Candidate masks of runs that need no tree walk (large-triangle words, runs of at most 8 small triangles) are
+    // collected in a window of 32 consecutive triangle indices and published together: adjacent short runs (the walls
+    // and the light of a room, split by the file order into three clusters) then cost one publication, not three.
+    uint32_t pend = 0, pend_tri0 = 0;   // per-lane bits; wave-uniform window start
+    bool pend_open = false;             // wave-uniform
+    auto flush_pending = [&]() {
+        if (pend_open) push_pairs_any(pend, pend_tri0, static_cast<uint32_t>(lane));
+        pend = 0;
+        pend_open = false;
+    };
+    auto add_pending = [&](uint32_t bits, uint32_t tri0, uint32_t width) {   // tri0, width wave-uniform
+        if (pend_open && tri0 >= pend_tri0 && tri0 + width <= pend_tri0 + 32u) {
+            pend |= bits << (tri0 - pend_tri0);
+        } else {
+            flush_pending();
+            pend = bits;
+            pend_tri0 = tri0;
+            pend_open = true;
+        }
+    };
+
     // ---- 1. cull
     const ConstF clusters = (ConstF)reinterpret_cast<uintptr_t>(a.clusters);
     const ConstF spheres = (ConstF)reinterpret_cast<uintptr_t>(a.spheres);
@@ -473,7 +494,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             PT_STAMP(st, 1);   // cluster + top-level sphere tests
             uint32_t n_nodes = 0;   // wave-uniform fill level of lds.nodes
             if (top == 0) {
-                push_pairs_any(tmask, first_tri, static_cast<uint32_t>(lane));   // the run has at most 8 triangles
+                add_pending(tmask, first_tri, n_tri);   // the run has at most 8 triangles
                 tmask = 0;
             } else {
                 while (__any(tmask != 0)) {   // at most 8 x 64 = 512 items > capacity: drained in the loop below before overflow
@@ -609,12 +630,13 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 m = pc ? m : 0u;
                 m &= left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
                 PT_STAMP(st, 3);   // barycentric cull of the large triangles
-                push_pairs_any(m, first_tri + kChunk * w, static_cast<uint32_t>(lane));
+                add_pending(m, first_tri + kChunk * w, min(left, 32u));
                 PT_STAMP(st, 4);   // pair publication
             }
         }
     }
     PT_STAMP(st, 1);
+    flush_pending();
     drain_pairs(0);
     if constexpr (Lds::kPrefilter) {
         if (n_filtered > 0) {
