@@ -306,6 +306,9 @@ struct Ignored {
 };
 struct NoStats {
     Ignored n_exact, w_segments, w_node_rounds, w_exact_iters, w_partial;
+#ifdef PT_PHASE_TIMERS
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;   // keeps the diagnostic build compiling; never launched there
+#endif
 };
 #ifdef PT_PHASE_TIMERS
 #define PT_STAMP(st, idx)                                              \
@@ -483,16 +486,81 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 lds.level_cnt[lane] = (n_tri + (1u << (3 * lane)) - 1u) >> (3 * lane);
             }
             wave_sync();
+            uint32_t n_nodes = 0;   // wave-uniform fill level of lds.nodes
+            uint32_t tmask = 0;
+            // (a') Few rays near a small tree: skip its top level.  The (at most 8) lanes that passed the cluster sphere are
+            // compacted, each gets 8 to 64 lanes, and together they test ALL nodes of the level below the top (at most
+            // 64) in one round -- instead of the wave-uniform top-level tests plus a round that is mostly empty.
+            bool rooted = false;
+            if (top >= 1) {
+                const unsigned long long pcb = __ballot(pc);
+                const uint32_t rcnt = __builtin_popcountll(pcb);
+                const uint32_t clev = top - 1;
+                const uint32_t nchild = (n_tri + (1u << (3 * clev)) - 1u) >> (3 * clev);
+                if (rcnt <= 8u && nchild <= 64u) {
+                    ++st.w_node_rounds;
+                    if (pc) lds.nodes[lanes_below(pcb)] = static_cast<uint32_t>(lane);   // the stack is empty here
+                    wave_sync();
+                    const uint32_t sh = rcnt <= 1u ? 6u : rcnt <= 2u ? 5u : rcnt <= 4u ? 4u : 3u;   // lanes per ray: 64, 32, 16, 8
+                    const uint32_t per = (nchild + (1u << sh) - 1u) >> sh;                       // nodes per lane: 1 .. 8
+                    const uint32_t item = static_cast<uint32_t>(lane) >> sh, c0 = (static_cast<uint32_t>(lane) & ((1u << sh) - 1u)) * per;
+                    uint32_t m = 0, src = 0;
+                    if (item < rcnt) {
+                        src = lds.nodes[item];
+                        Ray r;
+                        r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                        r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                        const float4 *cs = reinterpret_cast<const float4 *>(a.spheres) + off + lds.level_off[clev] + c0;
+                        auto test = [&](auto per_c) {
+                            constexpr uint32_t kPer = decltype(per_c)::value;
+#pragma unroll
+                            for (uint32_t i = 0; i < kPer; ++i) {
+                                if (c0 + i < nchild) {
+                                    const float4 sp = cs[i];
+                                    m |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << i) : 0u;
+                                }
+                            }
+                        };
+                        if (per == 1u) test(std::integral_constant<uint32_t, 1>());
+                        else if (per == 2u) test(std::integral_constant<uint32_t, 2>());
+                        else if (per <= 4u) test(std::integral_constant<uint32_t, 4>());
+                        else test(std::integral_constant<uint32_t, 8>());
+                    }
+                    wave_sync();   // every lane has read its ray's lane number before the stack is written
+                    const uint32_t tot = wave_sum(__builtin_popcount(m), 4);
+                    if (clev == 0) {   // the level below the top is the triangles themselves
+                        if (n_pairs + tot > kPairQueue) drain_pairs(0);
+                        if (tot <= kPairQueue) {
+                            push_pairs(m, first_tri + c0, src);
+                            rooted = true;
+                        }
+                    } else if (tot <= kNodeStack) {
+                        uint32_t nb = m;
+                        while (__any(nb != 0)) {
+                            const bool has = nb != 0;
+                            const unsigned long long ball = __ballot(has);
+                            if (has) {
+                                const uint32_t j = __builtin_ctz(nb);
+                                nb &= nb - 1;
+                                lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (clev << 23) | (c0 + j);
+                            }
+                            n_nodes += __builtin_popcountll(ball);
+                        }
+                        wave_sync();
+                        rooted = true;
+                    }
+                    // (more survivors than the queue holds: fall through to the general path below)
+                }
+            }
+            if (!rooted) {
             // (a) wave-uniform: every lane against the (at most 8) top-level spheres, records in SGPRs
             const uint32_t top_off = top == 0 ? 0u : ((ConstU)cp)[8 + top];
             const uint32_t top_cnt = (n_tri + (1u << (3 * top)) - 1u) >> (3 * top);
             const ConstF tp = spheres + 4 * (static_cast<size_t>(off) + top_off);
-            uint32_t tmask = 0;
             for (uint32_t j = 0; j < top_cnt; ++j)
                 tmask |= sphere_keep(tp[4 * j], tp[4 * j + 1], tp[4 * j + 2], tp[4 * j + 3], q) ? (1u << j) : 0u;
             tmask = pc ? tmask : 0u;
             PT_STAMP(st, 1);   // cluster + top-level sphere tests
-            uint32_t n_nodes = 0;   // wave-uniform fill level of lds.nodes
             if (top == 0) {
                 add_pending(tmask, first_tri, n_tri);   // the run has at most 8 triangles
                 tmask = 0;
@@ -509,6 +577,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     n_nodes += __builtin_popcountll(ball);
                 }
                 wave_sync();
+            }
             }
             // (b) lane-balanced expansion: lane l takes the l-th item from the top of the stack, tests the node's 8
             // children against that item's ray and pushes the survivors (tree nodes back on the stack, triangles as
