@@ -488,21 +488,21 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             wave_sync();
             uint32_t n_nodes = 0;   // wave-uniform fill level of lds.nodes
             uint32_t tmask = 0;
-            // (a') Few rays near a small tree: skip its top level.  The (at most 8) lanes that passed the cluster sphere are
-            // compacted, each gets 8 to 64 lanes, and together they test ALL nodes of the level below the top (at most
-            // 64) in one round -- instead of the wave-uniform top-level tests plus a round that is mostly empty.
+            // (a') Few rays near a small tree: skip its top level.  The (at most 16) lanes that passed the cluster sphere are
+            // compacted, each gets 4 to 64 lanes, and together they test ALL nodes of the level below the top (at most 8
+            // per lane) in one round -- instead of the wave-uniform top-level tests plus a round that is mostly empty.
             bool rooted = false;
             if (top >= 1) {
                 const unsigned long long pcb = __ballot(pc);
                 const uint32_t rcnt = __builtin_popcountll(pcb);
                 const uint32_t clev = top - 1;
                 const uint32_t nchild = (n_tri + (1u << (3 * clev)) - 1u) >> (3 * clev);
-                if (rcnt <= 8u && nchild <= 64u) {
+                const uint32_t sh = rcnt <= 1u ? 6u : rcnt <= 2u ? 5u : rcnt <= 4u ? 4u : rcnt <= 8u ? 3u : rcnt <= 16u ? 2u : 0u;   // lanes per ray
+                const uint32_t per = (nchild + (1u << sh) - 1u) >> sh;                                                           // nodes per lane
+                if (rcnt <= 16u && per <= 8u) {
                     ++st.w_node_rounds;
                     if (pc) lds.nodes[lanes_below(pcb)] = static_cast<uint32_t>(lane);   // the stack is empty here
                     wave_sync();
-                    const uint32_t sh = rcnt <= 1u ? 6u : rcnt <= 2u ? 5u : rcnt <= 4u ? 4u : 3u;   // lanes per ray: 64, 32, 16, 8
-                    const uint32_t per = (nchild + (1u << sh) - 1u) >> sh;                       // nodes per lane: 1 .. 8
                     const uint32_t item = static_cast<uint32_t>(lane) >> sh, c0 = (static_cast<uint32_t>(lane) & ((1u << sh) - 1u)) * per;
                     uint32_t m = 0, src = 0;
                     if (item < rcnt) {
