@@ -105,3 +105,38 @@ def test_replicated_scene_rays(tmp_path):
     tri, _ = o_scene.triangles()
     o, d = _adversarial_rays(tri, np.random.default_rng(6), 12_000)
     _check(g, o_scene, o, d)
+
+
+@pytest.mark.parametrize("n_tri,n_rays", [(512, 1), (512, 4), (512, 16), (512, 17), (64, 1), (64, 4), (64, 16), (40, 3), (9, 2)])
+def test_root_round_and_its_fallbacks(tmp_path, n_tri, n_rays):
+    """The root round of the tree walk (few rays near a small tree: the level below the top is tested in one
+    lane-spread round) and the cases it must hand back to the general path: a 'rod' of small triangles stacked along z
+    and rays fired down its axis, so that EVERY node of every level is kept for every ray -- with 4 rays and 64 nodes
+    below the top that is 256 survivors, more than either queue holds; 17 rays are one more than the round takes;
+    64 / 40 / 9 triangles make the level below the top the triangles themselves (pairs instead of nodes)."""
+    (tmp_path / "r.mtl").write_text("newmtl 0\nKd 0.5 0.5 0.5\n")
+    lines = ["mtllib r.mtl", "usemtl 0"]
+    for k in range(n_tri):
+        z = -10.0 + 0.02 * k
+        lines += [f"v -0.2 -0.15 {z:.6f}", f"v 0.2 -0.15 {z:.6f}", f"v 0.0 0.25 {z:.6f}", f"f {3 * k + 1} {3 * k + 2} {3 * k + 3}"]
+    (tmp_path / "r.obj").write_text("\n".join(lines) + "\n")
+    d = str(tmp_path) + "/"
+    g = pt.Scene.load_obj(d, "r.obj", device=0)
+    o = O.Scene.load(d, "r.obj")
+    t = g.cull_tables()
+    assert list(t["kind"]) == [0] and t["n_tri"][0] == n_tri
+    org = np.zeros((n_rays, 3), np.float32)
+    org[:, 0] = np.linspace(-0.05, 0.05, n_rays) if n_rays > 1 else 0.0
+    org[:, 2] = -15.0
+    dirs = _normalise(np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (n_rays, 1)) +
+                      np.linspace(0, 1e-3, n_rays, dtype=np.float32)[:, None] * np.array([[1.0, 0.5, 0.0]], np.float32))
+    gi, gt = g.trace_rays(org, dirs)
+    ri, rt, nan_seen = o.closest_hits(org, dirs)
+    assert not nan_seen.any()
+    assert np.array_equal(gi, ri) and np.array_equal(gt.view(np.uint32), rt.view(np.uint32))
+    assert (ri == 0).all()          # the first triangle of the rod is the closest hit of every ray
+    # and from the far end, where the LAST triangle is the answer (every candidate must have been examined)
+    org2 = org.copy(); org2[:, 2] = 5.0
+    gi, gt = g.trace_rays(org2, -dirs)
+    ri, rt, _ = o.closest_hits(org2, -dirs)
+    assert np.array_equal(gi, ri) and np.array_equal(gt.view(np.uint32), rt.view(np.uint32)) and (ri == n_tri - 1).all()
