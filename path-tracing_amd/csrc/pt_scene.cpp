@@ -328,6 +328,17 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         const double reff = sphere_of(i, 1, tmp);
         large[i] = !(reff < 0.12 * r_max);
     }
+    // A run of one or two small triangles between two large runs (the light of a room, listed between its walls) costs
+    // more as a cluster of its own -- descriptor, sphere tests, a publication -- than as one more record of the large run.
+    if (!std::getenv("PT_NO_ABSORB")) {
+        for (int b = 0; b < T;) {
+            int e = b;
+            while (e < T && large[e] == large[b]) ++e;
+            if (!large[b] && e - b <= 2 && b > 0 && e < T && !geo[b].degenerate && !geo[e - 1].degenerate)
+                for (int k = b; k < e; ++k) large[k] = 1;
+            b = e;
+        }
+    }
     // ---- clusters: maximal runs of consecutive triangles of one class
     const SphereRec never = {{0, 0, 0}, -1.0e30f};
     int i = 0;

@@ -39,15 +39,17 @@ def tor(models_dir):
 
 def test_structure_tor(tor):
     t = tor.cull_tables()
-    assert list(t["first_tri"]) == [0, 256, 258, 260] and list(t["n_tri"]) == [256, 2, 2, 10]
-    assert list(t["kind"]) == [0, 1, 0, 1]          # torus + light: spheres; walls: barycentric
-    assert list(t["n_levels"][[0, 2]]) == [3, 1]    # 256 -> 32 -> 4 nodes; the light's 2 triangles are their own top level
+    # torus: sphere tree.  The rest is ONE barycentric run: the file lists 2 wall triangles, the light's 2 triangles,
+    # then 10 wall triangles, and a run of <= 2 small triangles between two large runs is absorbed into them.
+    assert list(t["first_tri"]) == [0, 256] and list(t["n_tri"]) == [256, 14]
+    assert list(t["kind"]) == [0, 1]
+    assert t["n_levels"][0] == 3                    # 256 -> 32 -> 4 nodes
     assert list(t["level_off"][0][:3]) == [0, 256, 288]
-    assert t["n_large"] == 12
+    assert t["n_large"] == 14
     tri, _ = tor.triangles()
     v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
     lay = _layout(t)
-    assert sorted(lay) == list(range(256)) + [258, 259]
+    assert sorted(lay) == list(range(256))
     for i, (ci, chain) in lay.items():
         for sph in [t["cluster_sphere"][ci]] + [t["spheres"][k] for k in chain]:
             assert (((v[i] - sph[:3]) ** 2).sum(1) <= sph[3]).all()      # vertices inside every enclosing sphere
@@ -110,6 +112,14 @@ def test_degenerate_and_tiny_triangles_are_always_kept(tmp_path):
     assert sorted(lay) == [2] and np.isfinite(t["spheres"][lay[2][1][-1]][3])
 
 
+def test_light_as_its_own_cluster_without_absorption(models_dir, monkeypatch):
+    """PT_NO_ABSORB=1 (a tuning knob of the table builder) restores the four runs of the file order."""
+    monkeypatch.setenv("PT_NO_ABSORB", "1")
+    t = pt.Scene.load_obj(models_dir, "Tor.obj", device=-1).cull_tables()
+    assert list(t["first_tri"]) == [0, 256, 258, 260] and list(t["n_tri"]) == [256, 2, 2, 10]
+    assert list(t["kind"]) == [0, 1, 0, 1] and list(t["n_levels"][[0, 2]]) == [3, 1] and t["n_large"] == 12
+
+
 def test_tables_depend_on_eps(tor):
     a, b = tor.cull_tables(1e-4), tor.cull_tables(1e-2)
     assert (b["spheres"][:, 3] >= a["spheres"][:, 3]).all()
@@ -122,7 +132,7 @@ def test_quads_of_the_room_are_fused_and_never_cull_an_accepted_hit(tor, oracle_
     import ctypes as C
     t = tor.cull_tables()
     large = np.flatnonzero(t["kind"] == 1)
-    assert [int(t["level_off"][c][1]) for c in large] == [1, 0b101010101]      # quad masks of word 0: every wall pair fused
+    assert [int(t["level_off"][c][1]) for c in large] == [0b1010101010101]     # quad mask of word 0: walls and light, every pair fused
     k1, k2, a_max, m0 = (t["constants"][k] for k in ("k1", "k2", "a_max", "m0"))
     tri, _ = tor.triangles()
     v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
