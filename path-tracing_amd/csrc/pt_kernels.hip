@@ -503,7 +503,11 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     ++st.w_node_rounds;
                     if (pc) lds.nodes[lanes_below(pcb)] = static_cast<uint32_t>(lane);   // the stack is empty here
                     wave_sync();
-                    const uint32_t item = static_cast<uint32_t>(lane) >> sh, c0 = (static_cast<uint32_t>(lane) & ((1u << sh) - 1u)) * per;
+                    // Lane `sub` of a ray's group takes nodes sub, sub + group, sub + 2 group, ...: one load instruction then
+                    // reads consecutive records across the group (whole cache lines) instead of one line per lane.  When
+                    // the nodes are the triangles themselves the slices stay contiguous (pairs are published as bit masks).
+                    const uint32_t item = static_cast<uint32_t>(lane) >> sh, sub = static_cast<uint32_t>(lane) & ((1u << sh) - 1u);
+                    const uint32_t c0 = clev == 0 ? sub * per : sub, cstep = clev == 0 ? 1u : (1u << sh);
                     uint32_t m = 0, src = 0;
                     if (item < rcnt) {
                         src = lds.nodes[item];
@@ -515,8 +519,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                             constexpr uint32_t kPer = decltype(per_c)::value;
 #pragma unroll
                             for (uint32_t i = 0; i < kPer; ++i) {
-                                if (c0 + i < nchild) {
-                                    const float4 sp = cs[i];
+                                if (c0 + i * cstep < nchild) {
+                                    const float4 sp = cs[i * cstep];
                                     m |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << i) : 0u;
                                 }
                             }
@@ -542,7 +546,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                             if (has) {
                                 const uint32_t j = __builtin_ctz(nb);
                                 nb &= nb - 1;
-                                lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (clev << 23) | (c0 + j);
+                                lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (clev << 23) | (c0 + j * cstep);
                             }
                             n_nodes += __builtin_popcountll(ball);
                         }
@@ -617,11 +621,11 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                         const float4 *cs = reinterpret_cast<const float4 *>(a.spheres) + off + lds.level_off[level - 1] + child0;
                         auto test = [&](auto per_c) {
                             constexpr int per = decltype(per_c)::value;
-                            const uint32_t c_first = sub * per;
 #pragma unroll
                             for (int i = 0; i < per; ++i) {
-                                const float4 sp = cs[c_first + i];
-                                m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << (c_first + i)) : 0u;
+                                const uint32_t c = sub + (static_cast<uint32_t>(i) << shift);   // interleaved: the item's lanes read consecutive records
+                                const float4 sp = cs[c];
+                                m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << c) : 0u;
                             }
                         };
                         if (shift == 0u) test(std::integral_constant<int, 8>());
