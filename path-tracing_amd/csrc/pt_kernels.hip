@@ -49,6 +49,9 @@ struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = 
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+    // The ten round keys are wave-uniform and loop-invariant; hoisted out of the path loops they would sit in ten
+    // spilled SGPRs (a v_readlane + hazard nop each).  Opaque here, they are rebuilt with one scalar add per round.
+    asm volatile("" : "+s"(k0));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const unsigned long long p0 = static_cast<unsigned long long>(c0) * 0xD2511F53u;   // one v_mad_u64_u32 each
