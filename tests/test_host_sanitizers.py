@@ -1,0 +1,27 @@
+"""The host-side scene code (loader with the reference's token semantics, device tables, culling hierarchy incl. quad
+fusion and the big-scene tables) built with g++ -fsanitize=address,undefined and run on Tor.obj, on random scenes
+with degenerate triangles and on malformed OBJ files.  GPU sanitizers are not available on the pool; this is the CPU
+half (the kernels' indexing is covered by the parity and fuzz suites)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_scene_code_is_clean_under_asan_and_ubsan(tmp_path, models_dir):
+    exe = str(tmp_path / "scene_san")
+    csrc = os.path.join(ROOT, "path-tracing_amd", "csrc")
+    build = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-fno-omit-frame-pointer", "-I", csrc, os.path.join(ROOT, "tests", "native", "scene_sanitizer_main.cpp"),
+                            os.path.join(csrc, "pt_scene.cpp"), "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe, models_dir, str(tmp_path) + "/"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr
+    out = run.stdout
+    assert "eps 0.0001: 2 clusters" in out and "n 3000:" in out and "3004 bary_all" in out
+    assert out.count("bad obj -> 0") == 4 and "bad obj -> 1" in out        # four rejected with a message, the empty file loads (no triangles)
