@@ -44,6 +44,15 @@ def test_frame_is_deterministic_and_tiling_independent(frame):
     assert hashlib.sha256(acc[0].tobytes() + acc[1].tobytes() + acc[2].tobytes()).hexdigest() == digest
 
 
+def test_statistics_free_instantiation_renders_the_same_frame(frame):
+    """A caller that does not pass pt_render_stats runs a kernel instantiation without the diagnostic counters (the one
+    bench.py times); the frame must be the same bits."""
+    g, s, s2, c, st = frame
+    digest = hashlib.sha256(s.tobytes() + s2.tobytes() + c.tobytes()).hexdigest()
+    q = g.render_host(W, H, SPP, MRR, error=-1.0, seed=42, want_stats=False)[:3]
+    assert hashlib.sha256(q[0].tobytes() + q[1].tobytes() + q[2].tobytes()).hexdigest() == digest
+
+
 def test_sampled_rows_match_the_oracle(frame, oracle_scene):
     g, s, s2, c, st = frame
     for r0 in (0, 411, 540, 1078):        # top edge, torus, centre, bottom edge
