@@ -43,18 +43,21 @@ def max_band_floats(width, height, n_ranks):
     return max(band_floats(width, band_rows(height, n_ranks, r)[1] - band_rows(height, n_ranks, r)[0]) for r in range(n_ranks))
 
 
-def gather_bands(band, width, height, dist, rank, world, dst=0):
+def gather_bands(band, width, height, dist, rank, world, dst=0, out=None, async_op=False):
     """The one collective of a frame: every rank sends its packed band (a torch tensor, padded to the largest band)
-    to `dst`.  Returns the list of per-rank tensors on `dst`, None elsewhere."""
+    to `dst`.  Returns the list of per-rank tensors on `dst` (None elsewhere); with async_op=True returns
+    (that list, work handle) and the caller must keep `band` untouched and call work.wait() before using the result.
+    `out` lets `dst` reuse its receive buffers from frame to frame."""
     import torch
     n_max = max_band_floats(width, height, world)
     if band.numel() != n_max:
         padded = torch.zeros(n_max, dtype=band.dtype, device=band.device)
         padded[:band.numel()] = band
         band = padded
-    out = [torch.empty_like(band) for _ in range(world)] if rank == dst else None
-    dist.gather(band, out, dst=dst)
-    return out
+    if rank == dst and out is None:
+        out = [torch.empty_like(band) for _ in range(world)]
+    work = dist.gather(band, out if rank == dst else None, dst=dst, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def assemble(parts, width, height, world):

@@ -43,3 +43,23 @@ def test_bench_emits_one_valid_json_line():
     # the other two rates of SURVEY 8(d): PCIe-inclusive entry point and process start -> BMP
     assert 0 < j["pcie_inclusive"]["value"] <= j["value"] * 1.05
     assert j["end_to_end"]["value"] is not None and 0 < j["end_to_end"]["value"] < j["value"]
+
+
+def test_two_rank_rehearsal_frame_equals_single_process(tmp_path):
+    """bench.py's N > 1 code path (row bands, packed accumulators, the asynchronous gather pipelined over two band
+    buffers, assembly, resolve) with two ranks sharing this box's one GPU and gloo as the transport: the gathered
+    1920x2160 frame must be byte-identical to the stand-alone front end's render of the same frame."""
+    bmp = str(tmp_path / "two_ranks.bmp")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spp", "8",
+                        "--rehearse-on-one-gpu", "--write-bmp", bmp], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["height"] == 2160 and "REHEARSAL" in j["data"]
+    ref = str(tmp_path / "one_process.bmp")
+    exe = os.path.join(ROOT, "path-tracing_amd", "bin", "pt_render")
+    c = subprocess.run([exe, "--W", "1920", "--H", "2160", "-RPP", "8", "-MRR", "8", "-ERR", "-1", "-UPDATE", "0", "-QUIET", "1", "-SEED", "42",
+                        "-MODEL_PATH", os.path.join(ROOT, "models") + "/", "-OUT", ref], capture_output=True, text=True, cwd=tmp_path)
+    assert c.returncode == 0, c.stderr
+    assert open(bmp, "rb").read() == open(ref, "rb").read()
