@@ -12,8 +12,8 @@
 //             for operation (same association, no FMA contraction, IEEE divide and sqrt), and the closest hit per ray is
 //             taken with one LDS atomic-min on (distance, index), so `t`, the hit decision and the closest-hit choice
 //             are bit-identical to the CPU path.
-//   3. SHADE  Material::Process + the three lobes (material.h:36-102), Ray::Reflect (ray.h:45-50), accumulators in
-//             registers (material.h:74-77), counter-based Philox4x32-10 randoms keyed by (seed | pixel, pass, segment).
+//   3. SHADE  Material::Process + the three lobes (material.h:36-102), Ray::Reflect (ray.h:45-50), the tile's accumulators
+//             (material.h:74-77) in LDS, counter-based Philox4x32-10 randoms keyed by (seed | pixel, pass, segment).
 //
 // Everything that decides a result is plain IEEE binary32/binary64 arithmetic; only step 1 uses fused multiply-adds
 // and v_rcp_f32, and step 1 cannot change a result (DESIGN.md "Culling: why it cannot reject a hit").
