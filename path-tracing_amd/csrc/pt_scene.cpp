@@ -334,7 +334,11 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         for (int b = 0; b < T;) {
             int e = b;
             while (e < T && large[e] == large[b]) ++e;
-            if (!large[b] && e - b <= 2 && b > 0 && e < T && !geo[b].degenerate && !geo[e - 1].degenerate)
+            // ... unless they are so small that their barycentric gradients (1 / height) would blow up the margin of
+            // the whole class: the test of every large triangle uses the class-wide a_max
+            bool fits = !large[b] && e - b <= 2 && b > 0 && e < T;
+            for (int k = b; k < e && fits; ++k) fits = !geo[k].degenerate && geo[k].a_max * r_max <= 64.0;
+            if (fits)
                 for (int k = b; k < e; ++k) large[k] = 1;
             b = e;
         }

@@ -120,6 +120,20 @@ def test_light_as_its_own_cluster_without_absorption(models_dir, monkeypatch):
     assert list(t["kind"]) == [0, 1, 0, 1] and list(t["n_levels"][[0, 2]]) == [3, 1] and t["n_large"] == 12
 
 
+def test_tiny_run_between_walls_keeps_its_own_cluster(tmp_path):
+    """Absorption is refused when the small triangles' barycentric gradients would inflate the class-wide margin."""
+    (tmp_path / "w.mtl").write_text("newmtl 0\nKd 1 1 1\n")
+    quad = lambda z: [f"v -9 -9 {z}", f"v 9 -9 {z}", f"v 9 9 {z}", f"v -9 9 {z}"]
+    lines = ["mtllib w.mtl", "usemtl 0"] + quad(-9) + ["f 1 2 3", "f 1 3 4"]
+    lines += ["v 0 0 0", "v 0.05 0 0", "v 0 0.05 0", "f 5 6 7"]                       # a 5-centimetre triangle (smaller ones count as degenerate)
+    lines += quad(9) + ["f 8 9 10", "f 8 10 11"]
+    lines += ["v 0 0 1", "v 3 0 1", "v 0 3 1", "f 12 13 14"]                            # a 3-unit triangle: absorbed
+    lines += quad(5) + ["f 15 16 17", "f 15 17 18"]
+    (tmp_path / "w.obj").write_text("\n".join(lines) + "\n")
+    t = pt.Scene.load_obj(str(tmp_path) + "/", "w.obj", device=-1).cull_tables()
+    assert list(t["kind"]) == [1, 0, 1] and list(t["n_tri"]) == [2, 1, 5]
+
+
 def test_tables_depend_on_eps(tor):
     a, b = tor.cull_tables(1e-4), tor.cull_tables(1e-2)
     assert (b["spheres"][:, 3] >= a["spheres"][:, 3]).all()
