@@ -21,6 +21,7 @@
 
 #include <type_traits>
 
+#include "pt_fastfp.hpp"
 #include "pt_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -218,11 +219,17 @@ __device__ __forceinline__ bool cull_reject(const CullRec r, const Ray &q, float
 // 2. EXACT: Triangle::Intersect (triangles.h:48-73) with PlaneIntersect (:10-13) and ParallelogramSquare (:15-17).
 // Every operation is written in the reference's order; GLM's cross/length association is kept.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float area_of(float ax, float ay, float az, float bx, float by, float bz) {
+__device__ __forceinline__ float area2_of(float ax, float ay, float az, float bx, float by, float bz) {   // |a x b|^2
     const float cx = ay * bz - by * az;
     const float cy = az * bx - bz * ax;
     const float cz = ax * by - bx * ay;
-    return __builtin_sqrtf(cx * cx + cy * cy + cz * cz);
+    return cx * cx + cy * cy + cz * cz;
+}
+// IEEE sqrt / reciprocal with the lean sequences of pt_fastfp.hpp when every active lane's argument is in their
+// (exhaustively verified) range, the compiler's full expansion otherwise -- the result is the same bits either way.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    if (__all(fast_fp_ok(x))) return sqrt_rn_normal(x);
+    return __builtin_sqrtf(x);
 }
 
 // Stages B-D of Triangle::Intersect for one (ray, triangle) pair, without the running `distance`:
@@ -239,11 +246,18 @@ __device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, 
     const float f1x = px - r2.x, f1y = py - r2.y, f1z = pz - r2.z;
     const float f2x = px - r3.x, f2y = py - r3.y, f2z = pz - r3.z;
     const float sq = r1.w;
-    const float s1 = area_of(f0x, f0y, f0z, f1x, f1y, f1z);
+    const float q1 = area2_of(f0x, f0y, f0z, f1x, f1y, f1z);
+    const float q2 = area2_of(f0x, f0y, f0z, f2x, f2y, f2z);
+    const float q3 = area2_of(f2x, f2y, f2z, f1x, f1y, f1z);
+    float s1, s2, s3;
+    // one range check for the three roots: min and max of the squared areas decide for all of them
+    if (__all(fast_fp_ok(__builtin_fminf(__builtin_fminf(q1, q2), q3)) && fast_fp_ok(__builtin_fmaxf(__builtin_fmaxf(q1, q2), q3)))) {
+        s1 = sqrt_rn_normal(q1); s2 = sqrt_rn_normal(q2); s3 = sqrt_rn_normal(q3);
+    } else {
+        s1 = __builtin_sqrtf(q1); s2 = __builtin_sqrtf(q2); s3 = __builtin_sqrtf(q3);
+    }
     const bool stage_b = !(s1 > sq + eps);
-    const float s2 = area_of(f0x, f0y, f0z, f2x, f2y, f2z);
     const bool stage_c = !(s1 + s2 > sq + eps);
-    const float s3 = area_of(f2x, f2y, f2z, f1x, f1y, f1z);
     const bool stage_d = !(__builtin_fabsf(sq - s1 - s2 - s3) > eps);
     return (stage_b && stage_c && stage_d) ? nd : -__builtin_inff();
 }
@@ -264,7 +278,10 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // glm::normalize(vec4(x,y,z,0))
-    const float inv = 1.0f / __builtin_sqrtf((x * x + y * y) + z * z);
+    const float d = (x * x + y * y) + z * z;
+    float inv;
+    if (__all(fast_fp_ok(d))) inv = rcp_rn_normal(sqrt_rn_normal(d));   // the root of an in-range number is in range
+    else inv = 1.0f / __builtin_sqrtf(d);
     x = x * inv; y = y * inv; z = z * inv;
 }
 
@@ -823,7 +840,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
             q.dx = static_cast<float>((xi + jx) / wi - 0.5f);
             q.dy = static_cast<float>(-(yi + jy) / hi + 0.5f);
             q.dz = 1.0f;
-            const float inv = 1.0f / __builtin_sqrtf((q.dx * q.dx + q.dy * q.dy) + (1.0f * 1.0f + 0.0f * 0.0f));
+            const float inv = rcp_rn_normal(sqrt_rn_normal((q.dx * q.dx + q.dy * q.dy) + (1.0f * 1.0f + 0.0f * 0.0f)));   // 1 <= argument < 2
             q.dx = q.dx * inv; q.dy = q.dy * inv; q.dz = q.dz * inv;
             q.ox = 0.0f; q.oy = 0.0f; q.oz = -20.0f;
             depth = 0;
@@ -931,8 +948,8 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
                         const float ang = 2 * 3.141593f * xi2;
                         float sn, cs;
                         portable_sincos(ang, sn, cs);
-                        const float sq = __builtin_sqrtf(xi1);
-                        float rx = sq * cs, ry = sq * sn, rz = __builtin_sqrtf(1 - xi1);
+                        const float sq = sqrt_rn_normal(xi1);   // xi1 and 1 - xi1 are multiples of 2^-24 in [2^-24, 1)
+                        float rx = sq * cs, ry = sq * sn, rz = sqrt_rn_normal(1 - xi1);
                         normalize3(rx, ry, rz);
                         if ((pl.x * rx + pl.y * ry) + pl.z * rz < 0) { rx *= -1; ry *= -1; rz *= -1; }
                         float dt = (pl.x * rx + pl.y * ry) + pl.z * rz;
