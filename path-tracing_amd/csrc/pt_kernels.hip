@@ -15,8 +15,10 @@
 //   3. SHADE  Material::Process + the three lobes (material.h:36-102), Ray::Reflect (ray.h:45-50), the tile's accumulators
 //             (material.h:74-77) in LDS, counter-based Philox4x32-10 randoms keyed by (seed | pixel, pass, segment).
 //
-// Everything that decides a result is plain IEEE binary32/binary64 arithmetic; only step 1 uses fused multiply-adds
-// and v_rcp_f32, and step 1 cannot change a result (DESIGN.md "Culling: why it cannot reject a hit").
+// Everything that decides a result is plain IEEE binary32/binary64 arithmetic (float sqrt and reciprocal through
+// pt_fastfp.hpp: shorter sequences, verified against the correctly rounded result for every float of their range); only
+// step 1 uses fused multiply-adds and raw v_rcp_f32 results, and step 1 cannot change a result (DESIGN.md "Culling: why it
+// cannot reject a hit").
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
