@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -48,7 +48,8 @@ typedef enum pt_status {
     PT_ERR_PARSE = 3,          /* malformed OBJ/MTL: undefined behaviour in the reference */
     PT_ERR_NO_DEVICE = 4,
     PT_ERR_HIP = 5,
-    PT_ERR_OUT_OF_MEMORY = 6
+    PT_ERR_OUT_OF_MEMORY = 6,
+    PT_ERR_UNSUPPORTED = 7     /* a valid request this library does not implement (e.g. the reference's serial RNG streams) */
 } pt_status;
 
 typedef struct pt_scene pt_scene;   /* immutable after creation */
@@ -66,7 +67,19 @@ typedef struct pt_render_params {
     float eps;                      /* -EPS            config.h:22 */
     float error;                    /* -ERR            config.h:23 (adaptive sampling threshold; <0 disables) */
     uint32_t seed;                  /* -SEED           config.h:10 */
+    int32_t rng_policy;             /* PT_RNG_COUNTER (0, the default of a zeroed struct) or PT_RNG_REFERENCE_STREAM */
 } pt_render_params;
+
+/* Random-number policies.
+ * PT_RNG_COUNTER: stateless Philox4x32-10 keyed by (seed, global pixel, pass, segment) -- the policy the device
+ *   implements; results are independent of tiling, banding and GPU count.
+ * PT_RNG_REFERENCE_STREAM: the reference's two process-wide minstd_rand0 engines consumed in path order
+ *   (material.h:16-20, main.cpp:91-92,126-128).  Draw k of the stream belongs to whichever path asks k-th, so every
+ *   sample depends on all earlier ones: there is no parallel evaluation order, and the render entry points answer
+ *   PT_ERR_UNSUPPORTED.  (The CPU oracle implements it for the reference's recorded md5s; tests/test_gpu_rng_policy.py
+ *   states and checks the statistical tolerance between the two policies.) */
+#define PT_RNG_COUNTER 0
+#define PT_RNG_REFERENCE_STREAM 1
 
 typedef struct pt_render_stats {
     uint64_t samples_traced;        /* primary rays generated (adaptive skips excluded) */
@@ -81,6 +94,11 @@ typedef struct pt_render_stats {
     int32_t n_triangles;
     int32_t n_chunks;               /* pass-range chunks per pixel tile in this launch (each reads + writes the tile once) */
     int32_t partial_commit_rounds;  /* wave-level: tree-walk rounds that could not commit all 64 lanes (queues full) */
+    /* Verification build only (libpt_verify.so, -DPT_VERIFY_BRUTE; always 0 from the shipped library): after the culled
+     * search every segment's ray is also run through Triangle::Intersect against ALL triangles (scene.cpp:116-120 as
+     * written) on the device and the two closest hits are compared. */
+    uint64_t verify_checked;        /* segments compared */
+    uint64_t verify_mismatches;     /* segments whose (distance bits, triangle index) differed */
 } pt_render_stats;
 
 /* ---- scene ---------------------------------------------------------------------------------------- */
@@ -106,20 +124,45 @@ void pt_scene_destroy(pt_scene *scene);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */
 
-/* d_sum/d_sum2/d_count are DEVICE pointers on the scene's device, sized for the row band.  The kernel is
- * enqueued on `hip_stream` (a hipStream_t, NULL = the default stream) and the call returns without
- * synchronising unless `stats` is non-NULL (then it waits for the kernel and fills `stats`). */
+/* d_sum/d_sum2/d_count are DEVICE pointers on the scene's device, sized for the row band (any 4-byte alignment;
+ * 16-byte-aligned planes with width % 4 == 0 are written back with 16-byte stores).  The kernel is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the default stream) and the call returns without synchronising unless `stats`
+ * is non-NULL (then it waits for the kernel and fills `stats`). */
 int pt_render_device(pt_scene *scene, const pt_render_params *params, float *d_sum, float *d_sum2,
                      int32_t *d_count, void *hip_stream, pt_render_stats *stats);
 
-/* Same, with HOST buffers: uploads them, renders, downloads (PCIe-inclusive convenience path). */
+/* Same, with HOST buffers (PCIe-inclusive convenience path).  The band is cut into row slabs that are staged through
+ * pinned memory and uploaded / rendered / downloaded on three streams, so the transfers overlap the kernel; device
+ * and staging buffers are kept by the scene between calls. */
 int pt_render_host(pt_scene *scene, const pt_render_params *params, float *sum, float *sum2, int32_t *count,
                    pt_render_stats *stats);
 
+/* A render session keeps one row band's accumulators ON THE DEVICE between calls: the progressive driver
+ * (main.cpp:110-160: a preview every `update` passes, the -TL check before every pass) adds pass slices with
+ * pt_session_render and reads the band back only when it needs a preview or the final image.
+ * params->width/height/row_begin/row_end must equal the session's; pass_begin/pass_count select the slice. */
+typedef struct pt_session pt_session;
+int pt_session_create(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end,
+                      pt_session **out);                       /* accumulators start at zero */
+int pt_session_render(pt_session *session, const pt_render_params *params, pt_render_stats *stats);
+int pt_session_read(pt_session *session, float *sum, float *sum2, int32_t *count);   /* waits, then copies out */
+int pt_session_clear(pt_session *session);
+void pt_session_destroy(pt_session *session);
+
 /* Closest hit for caller-supplied rays: the triangle loop of Scene::TraceRay (scene.cpp:114-120) on the GPU.
- * origins/directions: 3 floats per ray (HOST buffers); directions must already be normalised the way Ray's
- * constructor does it (ray.h:23) -- the culling hierarchy assumes unit directions.  hit_index[i] = index of the
- * accepted triangle with the smallest distance (lowest index on ties) or -1, hit_t[i] = that distance (+inf on a miss). */
+ * origins/directions: 3 floats per ray (HOST buffers).  hit_index[i] = index of the accepted triangle with the
+ * smallest distance (lowest index on ties) or -1, hit_t[i] = that distance (+inf on a miss).
+ * The culling hierarchy's float-error margins are derived for the rays the integrator itself produces: unit
+ * directions (normalised as Ray's constructor does, ray.h:23) and origins with max |component| <= max(20, largest
+ * |vertex coordinate|) + 1 (the camera at (0,0,-20), or a point on a surface).  A ray outside that envelope
+ * (| |d|^2 - 1 | > 1e-5, a farther or a non-finite origin) is answered by the reference's own loop over ALL
+ * triangles on the device instead, so every finite ray gets the reference's answer; only the speed differs.
+ * eps < 0 is allowed and means what it means in the reference: the last test of Triangle::Intersect,
+ * abs(..) > eps (triangles.h:68), then rejects every triangle, so every ray misses.
+ * Known deviation: a ray lying EXACTLY in a triangle's stored plane makes PlaneIntersect (triangles.h:10-13) return
+ * 0/0 = NaN, which passes every comparison of Triangle::Intersect -- the reference then reports that triangle wherever
+ * it is.  No geometric cull can follow that; for such a ray this function returns the closest regular hit instead.
+ * The integrator cannot produce such rays (DESIGN.md "Known deviation"). */
 int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps,
                        int32_t *hit_index, float *hit_t);
 

@@ -19,11 +19,17 @@ LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "lib", "libpt_hip
 
 PT_OK = 0
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT_ERR_PARSE", 4: "PT_ERR_NO_DEVICE",
-                5: "PT_ERR_HIP", 6: "PT_ERR_OUT_OF_MEMORY"}
+                5: "PT_ERR_HIP", 6: "PT_ERR_OUT_OF_MEMORY", 7: "PT_ERR_UNSUPPORTED"}
+PT_ABI_VERSION = 2
+RNG_COUNTER, RNG_REFERENCE_STREAM = 0, 1
+# test-only builds of the same ABI (csrc/Makefile): never loaded by the product path
+VERIFY_LIB_PATH = os.path.join(_HERE, "lib", "libpt_verify.so")
+TESTHOOKS_LIB_PATH = os.path.join(_HERE, "lib", "libpt_testhooks.so")
 
 # every symbol include/pt_hip.h declares
 ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
                "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_trace_rays_host",
+               "pt_session_create", "pt_session_render", "pt_session_read", "pt_session_clear", "pt_session_destroy",
                "pt_scene_cull_tables", "pt_scene_set_skybox_bmp", "pt_resolve", "pt_resolve_float",
                "pt_post_filter_host", "pt_quantize",
                "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
@@ -38,14 +44,15 @@ class PtError(RuntimeError):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("pass_begin", C.c_int32), ("pass_count", C.c_int32), ("max_ray_reflections", C.c_int32),
-                ("eps", C.c_float), ("error", C.c_float), ("seed", C.c_uint32)]
+                ("eps", C.c_float), ("error", C.c_float), ("seed", C.c_uint32), ("rng_policy", C.c_int32)]
 
 
 class RenderStats(C.Structure):
     _fields_ = [("samples_traced", C.c_uint64), ("segments", C.c_uint64), ("contributing", C.c_uint64),
                 ("exact_tests", C.c_uint64), ("misses", C.c_uint64), ("wave_segments", C.c_uint64),
                 ("wave_node_rounds", C.c_uint64), ("wave_exact_iterations", C.c_uint64), ("kernel_ms", C.c_float),
-                ("n_triangles", C.c_int32), ("n_chunks", C.c_int32), ("partial_commit_rounds", C.c_int32)]
+                ("n_triangles", C.c_int32), ("n_chunks", C.c_int32), ("partial_commit_rounds", C.c_int32),
+                ("verify_checked", C.c_uint64), ("verify_mismatches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -86,39 +93,52 @@ def _share_torch_hip_runtime():
             pass
 
 
+def load_library(path):
+    """Load one build of the ABI (the product library by default; tests also load the verification / test-hook builds)."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: run `make -C {CSRC_DIR}` (there is no CPU fallback)")
+    _share_torch_hip_runtime()
+    L = C.CDLL(path)
+    fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
+    L.pt_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.pt_scene_create.argtypes = [fp, ip, C.c_int32, fp, C.c_int32, C.c_int, C.POINTER(vp)]
+    L.pt_scene_counts.argtypes = [vp, ip, ip]
+    L.pt_scene_get_triangles.argtypes = [vp, fp, ip]
+    L.pt_scene_get_materials.argtypes = [vp, fp]
+    L.pt_scene_destroy.argtypes = [vp]
+    L.pt_scene_destroy.restype = None
+    L.pt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, C.POINTER(RenderStats)]
+    L.pt_render_host.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.POINTER(RenderStats)]
+    L.pt_session_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.pt_session_render.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(RenderStats)]
+    L.pt_session_read.argtypes = [vp, fp, fp, ip]
+    L.pt_session_clear.argtypes = [vp]
+    L.pt_session_destroy.argtypes = [vp]
+    L.pt_session_destroy.restype = None
+    L.pt_trace_rays_host.argtypes = [vp, C.c_int32, fp, fp, C.c_float, ip, fp]
+    L.pt_scene_cull_tables.argtypes = [vp, C.c_float, ip, fp, fp, fp, fp]
+    L.pt_scene_set_skybox_bmp.argtypes = [vp, C.c_char_p]
+    L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
+    L.pt_resolve_float.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, fp, fp]
+    L.pt_post_filter_host.argtypes = [C.c_int, C.c_int32, C.c_int32, fp, C.c_int32, C.c_int32]
+    L.pt_quantize.argtypes = [C.c_int32, C.c_int32, fp, ip, C.POINTER(C.c_uint8)]
+    L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
+    L.pt_last_error.restype = C.c_char_p
+    if hasattr(L, "pt_test_set_mutation"):
+        L.pt_test_set_mutation.argtypes = [C.c_char_p, C.c_double]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FileNotFoundError(f"{LIB_PATH} is missing: run `make -C {CSRC_DIR}` (there is no CPU fallback)")
-        _share_torch_hip_runtime()
-        L = C.CDLL(LIB_PATH)
-        fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
-        L.pt_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
-        L.pt_scene_create.argtypes = [fp, ip, C.c_int32, fp, C.c_int32, C.c_int, C.POINTER(vp)]
-        L.pt_scene_counts.argtypes = [vp, ip, ip]
-        L.pt_scene_get_triangles.argtypes = [vp, fp, ip]
-        L.pt_scene_get_materials.argtypes = [vp, fp]
-        L.pt_scene_destroy.argtypes = [vp]
-        L.pt_scene_destroy.restype = None
-        L.pt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, C.POINTER(RenderStats)]
-        L.pt_render_host.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.POINTER(RenderStats)]
-        L.pt_trace_rays_host.argtypes = [vp, C.c_int32, fp, fp, C.c_float, ip, fp]
-        L.pt_scene_cull_tables.argtypes = [vp, C.c_float, ip, fp, fp, fp, fp]
-        L.pt_scene_set_skybox_bmp.argtypes = [vp, C.c_char_p]
-        L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
-        L.pt_resolve_float.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, fp, fp]
-        L.pt_post_filter_host.argtypes = [C.c_int, C.c_int32, C.c_int32, fp, C.c_int32, C.c_int32]
-        L.pt_quantize.argtypes = [C.c_int32, C.c_int32, fp, ip, C.POINTER(C.c_uint8)]
-        L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
-        L.pt_last_error.restype = C.c_char_p
-        _lib = L
+        _lib = load_library(LIB_PATH)
     return _lib
 
 
-def _check(status):
+def _check(status, L=None):
     if status != PT_OK:
-        raise PtError(status, lib().pt_last_error().decode(errors="replace"))
+        raise PtError(status, (L or lib()).pt_last_error().decode(errors="replace"))
 
 
 def _fp(a):
@@ -136,68 +156,71 @@ def device_count():
 class Scene:
     """Owns a pt_scene handle (Scene + LoadModel of the reference, scene.h:17-19)."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, library=None):
         self._h = handle
+        self._L = library or lib()
 
     @classmethod
-    def load_obj(cls, model_dir, model_name, device=0):
+    def load_obj(cls, model_dir, model_name, device=0, library=None):
+        L = library or lib()
         h = C.c_void_p()
-        _check(lib().pt_scene_load_obj(model_dir.encode(), model_name.encode(), device, C.byref(h)))
-        return cls(h)
+        _check(L.pt_scene_load_obj(model_dir.encode(), model_name.encode(), device, C.byref(h)), L)
+        return cls(h, L)
 
     @classmethod
-    def create(cls, triangles, triangle_material, materials, device=0):
+    def create(cls, triangles, triangle_material, materials, device=0, library=None):
+        L = library or lib()
         t = np.ascontiguousarray(triangles, np.float32).reshape(-1, 14)
         m = np.ascontiguousarray(triangle_material, np.int32)
         k = np.ascontiguousarray(materials, np.float32).reshape(-1, 10)
         h = C.c_void_p()
-        _check(lib().pt_scene_create(_fp(t), _ip(m), len(t), _fp(k), len(k), device, C.byref(h)))
-        return cls(h)
+        _check(L.pt_scene_create(_fp(t), _ip(m), len(t), _fp(k), len(k), device, C.byref(h)), L)
+        return cls(h, L)
 
     def counts(self):
         nt, nm = C.c_int32(), C.c_int32()
-        _check(lib().pt_scene_counts(self._h, C.byref(nt), C.byref(nm)))
+        _check(self._L.pt_scene_counts(self._h, C.byref(nt), C.byref(nm)), self._L)
         return nt.value, nm.value
 
     def triangles(self):
         nt, _ = self.counts()
         t = np.zeros((nt, 14), np.float32)
         m = np.zeros(nt, np.int32)
-        _check(lib().pt_scene_get_triangles(self._h, _fp(t), _ip(m)))
+        _check(self._L.pt_scene_get_triangles(self._h, _fp(t), _ip(m)), self._L)
         return t, m
 
     def materials(self):
         _, nm = self.counts()
         k = np.zeros((nm, 10), np.float32)
-        _check(lib().pt_scene_get_materials(self._h, _fp(k)))
+        _check(self._L.pt_scene_get_materials(self._h, _fp(k)), self._L)
         return k
 
     def render_host(self, width, height, spp, mrr, *, eps=1e-4, error=-1.0, seed=42, rows=None, pass_begin=0,
-                    accum=None, want_stats=True):
+                    accum=None, want_stats=True, rng_policy=RNG_COUNTER):
         r0, r1 = rows if rows is not None else (0, height)
         n = (r1 - r0) * width
         if accum is None:
             s, s2, c = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
         else:
             s, s2, c = accum
-        p = RenderParams(width, height, r0, r1, pass_begin, spp, mrr, eps, error, seed)
+        p = RenderParams(width, height, r0, r1, pass_begin, spp, mrr, eps, error, seed, rng_policy)
         st = RenderStats()
-        _check(lib().pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None))
+        _check(self._L.pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None), self._L)
         return s, s2, c, st.as_dict()
 
     def set_skybox(self, path):
         """-SKYBOX: a 24-bit BMP sampled by rays that hit nothing (scene.cpp:126-154); None or "" removes it."""
-        _check(lib().pt_scene_set_skybox_bmp(self._h, (path or "").encode()))
+        _check(self._L.pt_scene_set_skybox_bmp(self._h, (path or "").encode()), self._L)
 
     def cull_tables(self, eps=1e-4):
         """The culling hierarchy for `eps` (diagnostics): dict of clusters, spheres, bary records, constants."""
         counts = np.zeros(4, np.int32)
-        _check(lib().pt_scene_cull_tables(self._h, eps, _ip(counts), None, None, None, None))
+        _check(self._L.pt_scene_cull_tables(self._h, eps, _ip(counts), None, None, None, None), self._L)
         cl = np.zeros((counts[0], 16), np.float32)
         sp = np.zeros((counts[1], 4), np.float32)
         ba = np.zeros((counts[2], 12), np.float32)
         k = np.zeros(5, np.float32)
-        _check(lib().pt_scene_cull_tables(self._h, eps, _ip(counts), _fp(cl), _fp(sp), _fp(ba), _fp(k)))
+        _check(self._L.pt_scene_cull_tables(self._h, eps, _ip(counts), _fp(cl), _fp(sp), _fp(ba), _fp(k)), self._L)
         meta = cl[:, 4:16].view(np.uint32)
         return {"cluster_sphere": cl[:, :4], "first_tri": meta[:, 0].astype(int), "n_tri": meta[:, 1].astype(int),
                 "kind": meta[:, 2].astype(int), "data_off": meta[:, 3].astype(int), "n_levels": meta[:, 4].astype(int),
@@ -211,20 +234,57 @@ class Scene:
         d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
         idx = np.full(len(o), -2, np.int32)
         t = np.zeros(len(o), np.float32)
-        _check(lib().pt_trace_rays_host(self._h, len(o), _fp(o), _fp(d), eps, _ip(idx), _fp(t)))
+        _check(self._L.pt_trace_rays_host(self._h, len(o), _fp(o), _fp(d), eps, _ip(idx), _fp(t)), self._L)
         return idx, t
 
     def render_device(self, params, d_sum, d_sum2, d_count, stream=None, want_stats=False):
         """d_* are raw device pointers (ints), e.g. torch tensors' data_ptr(); stream is a hipStream_t value."""
         st = RenderStats()
-        _check(lib().pt_render_device(self._h, C.byref(params), C.c_void_p(d_sum), C.c_void_p(d_sum2),
+        _check(self._L.pt_render_device(self._h, C.byref(params), C.c_void_p(d_sum), C.c_void_p(d_sum2),
                                       C.c_void_p(d_count), C.c_void_p(stream or 0),
-                                      C.byref(st) if want_stats else None))
+                                      C.byref(st) if want_stats else None), self._L)
         return st.as_dict() if want_stats else None
 
     def close(self):
         if self._h:
-            lib().pt_scene_destroy(self._h)
+            self._L.pt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Session:
+    """pt_session: one row band's accumulators kept on the device between pass slices (progressive driver)."""
+
+    def __init__(self, scene, width, height, rows=None):
+        r0, r1 = rows if rows is not None else (0, height)
+        self._scene, self._L = scene, scene._L
+        self.width, self.height, self.rows = width, height, (r0, r1)
+        self._h = C.c_void_p()
+        _check(self._L.pt_session_create(scene._h, width, height, r0, r1, C.byref(self._h)), self._L)
+
+    def render(self, pass_begin, pass_count, mrr, *, eps=1e-4, error=-1.0, seed=42, want_stats=False):
+        p = RenderParams(self.width, self.height, self.rows[0], self.rows[1], pass_begin, pass_count, mrr, eps, error, seed, 0)
+        st = RenderStats()
+        _check(self._L.pt_session_render(self._h, C.byref(p), C.byref(st) if want_stats else None), self._L)
+        return st.as_dict() if want_stats else None
+
+    def read(self):
+        n = (self.rows[1] - self.rows[0]) * self.width
+        s, s2, c = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        _check(self._L.pt_session_read(self._h, _fp(s), _fp(s2), _ip(c)), self._L)
+        return s, s2, c
+
+    def clear(self):
+        _check(self._L.pt_session_clear(self._h), self._L)
+
+    def close(self):
+        if self._h:
+            self._L.pt_session_destroy(self._h)
             self._h = None
 
     def __del__(self):

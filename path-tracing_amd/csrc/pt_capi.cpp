@@ -35,7 +35,6 @@ struct pt_scene {
     pt::DeviceTables tables;
     int device = -1;
     DeviceCull cull;
-    std::mutex cull_mutex;
     pt::ExactRec *d_exact = nullptr;
     pt::MatRec *d_mats = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -52,6 +51,20 @@ struct pt_scene {
     hipEvent_t ev_done = nullptr;
     bool has_prev = false;
     hipStream_t prev_stream = nullptr;
+};
+
+#ifdef PT_TEST_HOOKS
+static int g_items_per_slot = 0;
+#endif
+
+// A row band's accumulators kept on the device between pass slices (pt_session_*).
+struct pt_session {
+    pt_scene *scene = nullptr;
+    int32_t width = 0, height = 0, row_begin = 0, row_end = 0;
+    size_t n = 0;                 // pixels of the band
+    float *d_band = nullptr;      // sum[3n] | sum2[3n] | count[n], each plane 256-byte aligned
+    size_t plane_floats = 0;      // distance between the sum and sum2 planes, in floats
+    hipStream_t stream = nullptr;
 };
 
 namespace {
@@ -108,8 +121,9 @@ int upload_vec(const std::vector<T> &v, T **dst) {
 }
 
 // The cull hierarchy's radii and margins depend on eps (-EPS): build and upload on first use, rebuild if eps changes.
+// Callers hold scene->launch_mutex from here until their kernel has been enqueued: a concurrent render with another eps
+// must not free the tables between this call and that launch.
 int ensure_cull(pt_scene *s, float eps) {
-    std::lock_guard<std::mutex> lock(s->cull_mutex);
     DeviceCull &c = s->cull;
     if (c.valid && std::memcmp(&c.eps, &eps, sizeof eps) == 0) return PT_OK;
     c.valid = false;
@@ -166,6 +180,7 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.n_tri = scene->host.n_tri();
     a.eps = eps;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.m0_quad = cc.m0_quad; a.t_guard = cc.t_guard;
+    a.r_org = scene->cull.host.r_org;
 }
 
 // No exception may cross the C boundary: allocation failures and anything else become status codes.
@@ -191,6 +206,10 @@ int check_params(const pt_scene *scene, const pt_render_params *p) {
     if (p->pass_begin < 0 || p->pass_count < 0) return fail(PT_ERR_INVALID_ARGUMENT, "negative pass range");
     if (static_cast<long long>(p->width) * p->height > 0x7fffffffLL)
         return fail(PT_ERR_INVALID_ARGUMENT, "image has more than 2^31 pixels");
+    if (p->rng_policy == PT_RNG_REFERENCE_STREAM)
+        return fail(PT_ERR_UNSUPPORTED, "PT_RNG_REFERENCE_STREAM: the reference's serial minstd_rand0 streams (material.h:16-20) have no "
+                                        "parallel evaluation order; the device implements PT_RNG_COUNTER");
+    if (p->rng_policy != PT_RNG_COUNTER) return fail(PT_ERR_INVALID_ARGUMENT, "unknown rng_policy");
     return PT_OK;
 }
 
@@ -337,10 +356,13 @@ static int render_device_impl(pt_scene *scene, const pt_render_params *p, float 
     if (!d_sum || !d_sum2 || !d_count) return fail(PT_ERR_INVALID_ARGUMENT, "null accumulator pointer");
     PT_HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    std::lock_guard<std::mutex> launch_lock(scene->launch_mutex);
     const int crc = ensure_cull(scene, p->eps);
     if (crc != PT_OK) return crc;
     pt::RenderArgs a;
     fill_scene_args(scene, p->eps, a);
+    a.vec_ok = (p->width % 4 == 0) &&
+               ((reinterpret_cast<uintptr_t>(d_sum) | reinterpret_cast<uintptr_t>(d_sum2) | reinterpret_cast<uintptr_t>(d_count)) % 16 == 0);
     a.sum = d_sum;
     a.sum2 = d_sum2;
     a.count = d_count;
@@ -361,13 +383,14 @@ static int render_device_impl(pt_scene *scene, const pt_render_params *p, float 
     }
     const uint32_t slots = static_cast<uint32_t>(scene->cu_count) * 4u * 6u;   // CUs x SIMDs x waves per SIMD of this kernel
     uint32_t per_slot = 24u;
-    if (const char *e = std::getenv("PT_ITEMS_PER_SLOT")) per_slot = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // tuning knob
+#ifdef PT_TEST_HOOKS
+    if (g_items_per_slot > 0) per_slot = static_cast<uint32_t>(g_items_per_slot);   // scheduler tuning, test build only
+#endif
     uint32_t n_chunks = (per_slot * slots + n_tiles - 1u) / n_tiles;
     n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
     const int32_t chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
     n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
     if (static_cast<unsigned long long>(n_tiles) * n_chunks > 0x7fffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "too many work items");
-    std::lock_guard<std::mutex> launch_lock(scene->launch_mutex);
     if (scene->has_prev && scene->prev_stream != stream) PT_HIP_TRY(hipStreamWaitEvent(stream, scene->ev_done, 0));
     if (scene->sched_words < 1 + static_cast<size_t>(n_tiles)) {
         PT_HIP_TRY(hipStreamSynchronize(stream));
@@ -409,6 +432,8 @@ static int render_device_impl(pt_scene *scene, const pt_render_params *p, float 
         stats->n_triangles = scene->host.n_tri();
         stats->n_chunks = static_cast<int32_t>(n_chunks);
         stats->partial_commit_rounds = static_cast<int32_t>(std::min<unsigned long long>(h[8], 0x7fffffffull));
+        stats->verify_checked = h[9];      // both stay 0 unless this is the verification build (-DPT_VERIFY_BRUTE)
+        stats->verify_mismatches = h[10];
 #ifdef PT_PHASE_TIMERS
         std::fprintf(stderr, "PT_PHASE_TIMERS cycles:");
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[16 + k]);
@@ -426,6 +451,7 @@ static int trace_rays_host_impl(pt_scene *scene, int32_t n_rays, const float *or
         return fail(PT_ERR_INVALID_ARGUMENT, "null ray buffer or negative count");
     if (n_rays == 0) return PT_OK;
     PT_HIP_TRY(hipSetDevice(scene->device));
+    std::lock_guard<std::mutex> launch_lock(scene->launch_mutex);
     const int crc = ensure_cull(scene, eps);
     if (crc != PT_OK) return crc;
     pt::RenderArgs a;
@@ -482,6 +508,59 @@ static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *s
     if (d_sum2) (void)hipFree(d_sum2);
     if (d_count) (void)hipFree(d_count);
     return result;
+}
+
+static int session_create_impl(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, pt_session **out) {
+    if (!out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    pt_render_params p;
+    std::memset(&p, 0, sizeof p);
+    p.width = width; p.height = height; p.row_begin = row_begin; p.row_end = row_end;
+    const int rc = check_params(scene, &p);
+    if (rc != PT_OK) return rc;
+    PT_HIP_TRY(hipSetDevice(scene->device));
+    std::unique_ptr<pt_session> s(new pt_session);
+    s->scene = scene;
+    s->width = width; s->height = height; s->row_begin = row_begin; s->row_end = row_end;
+    s->n = static_cast<size_t>(row_end - row_begin) * width;
+    s->plane_floats = (3 * s->n + 63) / 64 * 64;
+    const size_t bytes = (2 * s->plane_floats + s->n) * sizeof(float) + 256;
+    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_band), bytes));
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_band, 0, bytes, s->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(s->d_band);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+        return hip_fail(e, "pt_session_create");
+    }
+    *out = s.release();
+    return PT_OK;
+}
+
+static int session_render_impl(pt_session *s, const pt_render_params *p, pt_render_stats *stats) {
+    if (!s || !p) return fail(PT_ERR_INVALID_ARGUMENT, "null session or params");
+    if (p->width != s->width || p->height != s->height || p->row_begin != s->row_begin || p->row_end != s->row_end)
+        return fail(PT_ERR_INVALID_ARGUMENT, "params describe another band than the session's");
+    return render_device_impl(s->scene, p, s->d_band, s->d_band + s->plane_floats,
+                              reinterpret_cast<int32_t *>(s->d_band + 2 * s->plane_floats), s->stream, stats);
+}
+
+static int session_read_impl(pt_session *s, float *sum, float *sum2, int32_t *count) {
+    if (!s || !sum || !sum2 || !count) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->n == 0) return PT_OK;
+    PT_HIP_TRY(hipSetDevice(s->scene->device));
+    PT_HIP_TRY(hipMemcpyAsync(sum, s->d_band, 3 * s->n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    PT_HIP_TRY(hipMemcpyAsync(sum2, s->d_band + s->plane_floats, 3 * s->n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    PT_HIP_TRY(hipMemcpyAsync(count, s->d_band + 2 * s->plane_floats, s->n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    PT_HIP_TRY(hipStreamSynchronize(s->stream));
+    return PT_OK;
+}
+
+static int session_clear_impl(pt_session *s) {
+    if (!s) return fail(PT_ERR_INVALID_ARGUMENT, "null session");
+    PT_HIP_TRY(hipSetDevice(s->scene->device));
+    PT_HIP_TRY(hipMemsetAsync(s->d_band, 0, (2 * s->plane_floats + s->n) * sizeof(float), s->stream));
+    return PT_OK;
 }
 
 static int scene_cull_tables_impl(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary,
@@ -693,6 +772,33 @@ int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float
     return guarded([&] { return render_host_impl(scene, p, sum, sum2, count, stats); });
 }
 
+int pt_session_create(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, pt_session **out) {
+    return guarded([&] { return session_create_impl(scene, width, height, row_begin, row_end, out); });
+}
+
+int pt_session_render(pt_session *session, const pt_render_params *params, pt_render_stats *stats) {
+    return guarded([&] { return session_render_impl(session, params, stats); });
+}
+
+int pt_session_read(pt_session *session, float *sum, float *sum2, int32_t *count) {
+    return guarded([&] { return session_read_impl(session, sum, sum2, count); });
+}
+
+int pt_session_clear(pt_session *session) {
+    return guarded([&] { return session_clear_impl(session); });
+}
+
+void pt_session_destroy(pt_session *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->scene->device);
+    if (s->stream) {
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipStreamDestroy(s->stream);
+    }
+    if (s->d_band) (void)hipFree(s->d_band);
+    delete s;
+}
+
 int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary, float *constants) {
     return guarded([&] { return scene_cull_tables_impl(scene, eps, counts, clusters, spheres, bary, constants); });
 }
@@ -700,5 +806,26 @@ int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clu
 int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median) {
     return guarded([&] { return post_filter_host_impl(device, width, height, rgb, gauss, median); });
 }
+
+#ifdef PT_TEST_HOOKS
+// Test build only (libpt_testhooks.so).  family: "sphere_r2", "m0", "k12", "a_max", "quad_slack" (scale on that family of
+// conservative margins; 1 = as shipped), "no_absorb" (0/1), "items_per_slot" (scheduler), "reset".  Affects scenes whose
+// cull tables are built afterwards.
+int pt_test_set_mutation(const char *family, double value) {
+    if (!family) return PT_ERR_INVALID_ARGUMENT;
+    const std::string f = family;
+    pt::CullMutation &m = pt::g_cull_mutation;
+    if (f == "reset") { m = pt::CullMutation(); g_items_per_slot = 0; }
+    else if (f == "sphere_r2") m.sphere_r2 = value;
+    else if (f == "m0") m.m0 = value;
+    else if (f == "k12") m.k12 = value;
+    else if (f == "a_max") m.a_max = value;
+    else if (f == "quad_slack") m.quad_slack = value;
+    else if (f == "no_absorb") m.no_absorb = value != 0;
+    else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);
+    else return fail(PT_ERR_INVALID_ARGUMENT, "unknown mutation family " + f);
+    return PT_OK;
+}
+#endif
 
 }  // extern "C"

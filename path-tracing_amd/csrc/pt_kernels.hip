@@ -312,6 +312,9 @@ struct WaveLds {
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0, w_partial = 0;   // wave-uniform, live in SGPRs
+#ifdef PT_VERIFY_BRUTE
+    uint32_t v_checked = 0, v_bad = 0;   // verification build: segments compared with the brute-force loop / differing
+#endif
 #ifdef PT_PHASE_TIMERS
     // diagnostic build only: shader-clock cycles per phase (never compiled into the shipped library)
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -328,6 +331,9 @@ struct Ignored {
 };
 struct NoStats {
     Ignored n_exact, w_segments, w_node_rounds, w_exact_iters, w_partial;
+#ifdef PT_VERIFY_BRUTE
+    Ignored v_checked, v_bad;   // keeps the verification build compiling; it always launches the STATS instantiations
+#endif
 #ifdef PT_PHASE_TIMERS
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;   // keeps the diagnostic build compiling; never launched there
 #endif
@@ -359,6 +365,22 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// Scene::TraceRay's triangle loop exactly as the reference runs it (scene.cpp:116-120): every triangle, in index order,
+// through Triangle::Intersect for this lane's ray; returns the closest-hit key (~0 = miss).  Wave-uniform control flow.
+// Used for rays outside the envelope the culling margins were derived for (pt_trace_rays_host) and by the verification
+// build; the integrator's shipped instantiations never call it.
+__device__ __noinline__ unsigned long long brute_force_key(const RenderArgs &a, const Ray &q, float eps) {
+    unsigned long long best = ~0ull;
+    for (int i = 0; i < a.n_tri; ++i) {
+        const float nd = exact_inside(a.exact + i, q, eps);
+        if (nd >= eps && nd < __builtin_inff()) {
+            const unsigned long long k = (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | static_cast<uint32_t>(i);
+            best = k < best ? k : best;
+        }
+    }
+    return best;
 }
 
 template <class Lds, class Stats>
@@ -743,6 +765,15 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     }
     PT_STAMP(st, 5);   // exact rounds
     const unsigned long long key = lds.best[lane];
+#ifdef PT_VERIFY_BRUTE
+    // Verification build (libpt_verify.so, never the shipped library): Scene::TraceRay's loop as written -- every
+    // triangle through Triangle::Intersect for this lane's own ray -- and a comparison of the two closest hits.
+    {
+        const unsigned long long brute = brute_force_key(a, q, eps);
+        st.v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid)));
+        st.v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid && brute != key)));
+    }
+#endif
     hit = (key == ~0ull) ? -1 : static_cast<int>(key & 0xFFFFFFFFu);
     best = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
     wave_sync();
@@ -973,7 +1004,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
     // (a row of the tile is kTileW*12 contiguous bytes of sum / sum2 and kTileW*4 of count): dword stores at a 12-byte
     // stride made the memory side see about twice the bytes.
     const int tile_x = static_cast<int>(tile % a.blocks_x) * kTileW, tile_y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;
-    const bool whole = (a.width % 4 == 0) && tile_x + kTileW <= a.width && tile_y + kTileH <= a.row_end;   // wave-uniform
+    const bool whole = a.vec_ok && tile_x + kTileW <= a.width && tile_y + kTileH <= a.row_end;   // wave-uniform
     wave_sync();
     if (whole) {
         constexpr int kRowVec = kTileW * 3 / 4;          // float4 per tile row of a colour plane
@@ -1027,6 +1058,10 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         atomicAdd(&a.stats[6], static_cast<unsigned long long>(wst.w_node_rounds));
         atomicAdd(&a.stats[7], static_cast<unsigned long long>(wst.w_exact_iters));
         if (wst.w_partial) atomicAdd(&a.stats[8], static_cast<unsigned long long>(wst.w_partial));
+#ifdef PT_VERIFY_BRUTE
+        atomicAdd(&a.stats[9], static_cast<unsigned long long>(wst.v_checked));
+        if (wst.v_bad) atomicAdd(&a.stats[10], static_cast<unsigned long long>(wst.v_bad));
+#endif
 #ifdef PT_PHASE_TIMERS
         for (int k = 0; k < 8; ++k) atomicAdd(&a.stats[16 + k], wst.phase[k]);
 #endif
@@ -1047,10 +1082,22 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void trace_rays_kernel(c
         q.ox = origins[3 * i]; q.oy = origins[3 * i + 1]; q.oz = origins[3 * i + 2];
         q.dx = directions[3 * i]; q.dy = directions[3 * i + 1]; q.dz = directions[3 * i + 2];
     }
+    // Rays outside the envelope the culling margins were derived for (pt_hip.h: pt_trace_rays_host) take the reference's
+    // loop over all triangles instead; written so that NaNs count as outside.
+    const float d2 = (q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz;
+    const bool inside = __builtin_fabsf(q.ox) <= a.r_org && __builtin_fabsf(q.oy) <= a.r_org && __builtin_fabsf(q.oz) <= a.r_org &&
+                        __builtin_fabsf(d2 - 1.0f) <= 1.0e-5f;
     float best;
     int hit;
     WaveStats st;
-    closest_hit(a, lds, q, valid, lane, a.eps, best, hit, st);
+    closest_hit(a, lds, q, valid && inside, lane, a.eps, best, hit, st);
+    if (__any(valid && !inside)) {
+        const unsigned long long key = brute_force_key(a, q, a.eps);
+        if (!inside) {
+            hit = (key == ~0ull) ? -1 : static_cast<int>(key & 0xFFFFFFFFu);
+            best = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
+        }
+    }
     if (valid) {
         hit_index[i] = hit;
         hit_t[i] = best;
@@ -1071,7 +1118,7 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     if (rows <= 0 || args.width <= 0) return hipSuccess;
     const unsigned grid = args.n_tiles * args.n_chunks;
     const bool big = args.n_tri > kBigSceneTriangles;
-#ifdef PT_PHASE_TIMERS
+#if defined(PT_PHASE_TIMERS) || defined(PT_VERIFY_BRUTE)
     const bool stats = true;
 #else
     const bool stats = args.stats != nullptr;

@@ -22,7 +22,7 @@ struct RenderArgs {
     int32_t sky_w, sky_h;
     float *sum, *sum2;        // row band, 3 floats per pixel
     int32_t *count;
-    unsigned long long *stats;   // 24 counters (9 used; 16.. = phase timers of diagnostic builds) or nullptr
+    unsigned long long *stats;   // 24 counters (11 used; 16.. = phase timers of diagnostic builds) or nullptr
     int32_t n_clusters, n_tri;
     int32_t width, height, row_begin, row_end;
     int32_t pass_begin, pass_count, mrr;
@@ -33,6 +33,8 @@ struct RenderArgs {
     uint32_t *sched;                    // [0] ticket counter, [1 + tile] chunks of that tile already published; zeroed per launch
     uint32_t n_tiles, n_chunks;         // work items = n_tiles * n_chunks, chunk-major
     int32_t chunk_passes;               // passes per chunk
+    int32_t vec_ok;                     // sum / sum2 / count are 16-byte aligned and width % 4 == 0: 16-byte write-back allowed
+    float r_org;                        // origins with a component beyond this are outside the cull margins' envelope
 };
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);

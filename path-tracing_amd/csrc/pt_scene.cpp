@@ -198,6 +198,10 @@ void build_device_tables(const HostScene &s, DeviceTables &out) {
     }
 }
 
+#ifdef PT_TEST_HOOKS
+CullMutation g_cull_mutation;
+#endif
+
 namespace {
 
 struct V3 {
@@ -286,6 +290,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     for (int i = 0; i < T; ++i)
         for (int k = 4; k < 13; ++k) r_max = std::max(r_max, static_cast<double>(std::fabs(s.tri[14 * static_cast<size_t>(i) + k])));
     const double r_org = r_max + 1.0;                       // ray origins sit on surfaces, offset by eps*N
+    out.r_org = static_cast<float>(r_org);
     const double d_max = 2.0 * std::sqrt(3.0) * r_org;      // bound on |c - o| for c, o inside the scene box
     // rounding of P* = o + d*t* (per component <= u(2|t| + |o|)) and of the centre-to-origin vector
     const double eps_line = 8.0 * kU * (d_max + r_org);
@@ -315,7 +320,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         // the centre is rounded to float: grow by that displacement
         const double c_round = nrm(sub(c, V3{rec.c[0], rec.c[1], rec.c[2]}));
         double r2 = (reff + c_round) * (reff + c_round) * (1.0 + 1e-6) + disc_err;
-        if (const char *e = std::getenv("PT_MUTATE_SPHERE_R2")) r2 *= std::atof(e);   // mutation testing only
+        r2 *= PT_MUT(sphere_r2);
         rec.r2 = (inf || !std::isfinite(r2)) ? INFINITY : static_cast<float>(r2 * (1.0 + 2e-7));
         return inf ? INFINITY : reff;
     };
@@ -330,7 +335,12 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     }
     // A run of one or two small triangles between two large runs (the light of a room, listed between its walls) costs
     // more as a cluster of its own -- descriptor, sphere tests, a publication -- than as one more record of the large run.
-    if (!std::getenv("PT_NO_ABSORB")) {
+#ifdef PT_TEST_HOOKS
+    const bool absorb = !g_cull_mutation.no_absorb;
+#else
+    const bool absorb = true;
+#endif
+    if (absorb) {
         for (int b = 0; b < T;) {
             int e = b;
             while (e < T && large[e] == large[b]) ++e;
@@ -521,20 +531,20 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     // ---- margins of the barycentric test (large triangles)
     const double m_abs = 2.0 * std::sqrt(3.0) * r_org;   // bound on |o.n| + |w|
     CullConstants &cc = out.cc;
-    cc.k2 = static_cast<float>(12.0 * kU * m_abs + 8.0 * kU * r_org);
-    cc.k1 = static_cast<float>(40.0 * kU);
-    cc.a_max = static_cast<float>(a_max * (1.0 + 1e-6));
-    cc.m0 = static_cast<float>(std::fabs(eps) * inv_2s_max * 1.01 + 40.0 * kU * diam2_2s_max
-                               + 16.0 * kU * a_max * r_org * std::sqrt(3.0) + 1e-6);
+    cc.k2 = static_cast<float>(PT_MUT(k12) * (12.0 * kU * m_abs + 8.0 * kU * r_org));
+    cc.k1 = static_cast<float>(PT_MUT(k12) * 40.0 * kU);
+    cc.a_max = static_cast<float>(PT_MUT(a_max) * a_max * (1.0 + 1e-6));
+    cc.m0 = static_cast<float>(PT_MUT(m0) * (std::fabs(eps) * inv_2s_max * 1.01 + 40.0 * kU * diam2_2s_max
+                                             + 16.0 * kU * a_max * r_org * std::sqrt(3.0) + 1e-6));
     double tg = 4096.0 * r_org;
     if (a_max > 0) tg = std::min(tg, 1.0e6 / a_max);   // keep the reference's own area arithmetic meaningful
     cc.t_guard = static_cast<float>(tg);
-    cc.m0_quad = static_cast<float>(static_cast<double>(cc.m0) + quad_slack * 1.01 + 8.0 * kU * a_max * r_org);
+    cc.m0_quad = static_cast<float>(static_cast<double>(cc.m0) + PT_MUT(quad_slack) * (quad_slack * 1.01 + 8.0 * kU * a_max * r_org));
     // the same margins over ALL triangles (pair pre-filter of big scenes)
     out.cc_all = cc;
-    out.cc_all.a_max = static_cast<float>(a_max_all * (1.0 + 1e-6));
-    out.cc_all.m0 = static_cast<float>(std::fabs(eps) * inv_2s_max_all * 1.01 + 40.0 * kU * diam2_2s_max_all
-                                       + 16.0 * kU * a_max_all * r_org * std::sqrt(3.0) + 1e-6);
+    out.cc_all.a_max = static_cast<float>(PT_MUT(a_max) * a_max_all * (1.0 + 1e-6));
+    out.cc_all.m0 = static_cast<float>(PT_MUT(m0) * (std::fabs(eps) * inv_2s_max_all * 1.01 + 40.0 * kU * diam2_2s_max_all
+                                                     + 16.0 * kU * a_max_all * r_org * std::sqrt(3.0) + 1e-6));
     double tga = 4096.0 * r_org;
     if (a_max_all > 0) tga = std::min(tga, 1.0e6 / a_max_all);
     out.cc_all.t_guard = static_cast<float>(tga);

@@ -97,7 +97,21 @@ struct CullTables {
     std::vector<ClusterDesc> clusters;
     CullConstants cc;
     float eps = 0;
+    float r_org = 0;                 // the margins hold for ray origins with every |component| <= r_org
 };
+
+#ifdef PT_TEST_HOOKS
+// Test build only (libpt_testhooks.so): scale factors on each family of conservative margins, so that the test suite can
+// show it notices a cull that is too tight (tests/test_gpu_mutation.py).  The shipped library has no such knob.
+struct CullMutation {
+    double sphere_r2 = 1, m0 = 1, k12 = 1, a_max = 1, quad_slack = 1;
+    int no_absorb = 0;
+};
+extern CullMutation g_cull_mutation;
+#define PT_MUT(field) (::pt::g_cull_mutation.field)
+#else
+#define PT_MUT(field) 1.0
+#endif
 
 struct DeviceTables {
     std::vector<ExactRec> exact;   // n_tri

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Generates tor_reference_stream_128x128.npz: the converged Tor.obj image under the REFERENCE's random streams.
+
+north_star asks that the GPU image "match the reference CPU render on identical RNG seeds within a stated per-channel
+tolerance".  Under the counter policy the GPU is bit-identical to the oracle (tolerance 0, tests/test_gpu_parity.py);
+under the reference's own policy -- two process-wide minstd_rand0 streams consumed in path order (material.h:16-20,
+main.cpp:91-92,126-128) with libm sinf/cosf -- no parallel machine can reproduce the draw order, so the two renders
+are two independent Monte-Carlo estimates of the same image and the tolerance is statistical.  This fixture is the
+oracle in exactly that mode (ORC_RNG_SEQUENTIAL + ORC_TRIG_LIBM, one thread: the only mode tied to the reference's
+recorded BMP md5s, tests/test_oracle_known_answers.py), rendered once per seed and summed:
+
+    128 x 128 pixels, -MRR 8, -ERR -1, -EPS 1e-4, seeds 42..49, 512 passes each  (= 4096 samples per pixel)
+
+Runs the eight seeds in eight processes (the sequential policy is single-threaded by construction): ~4 minutes.
+
+    python tests/golden/make_rng_policy_fixture.py
+
+tests/test_gpu_rng_policy.py renders the same seeds on the GPU under the counter policy and compares.
+"""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W = H = 128
+MRR = 8
+SEEDS = list(range(42, 50))
+PASSES = 512
+
+
+def one_seed(seed):
+    import oracle_lib as O
+    sc = O.Scene.load(os.path.join(ROOT, "models") + "/", "Tor.obj")
+    s, s2, c, st = O.render(sc, W, H, PASSES, MRR, error=-1.0, seed=seed, rng=O.RNG_SEQUENTIAL, trig=O.TRIG_LIBM, threads=1)
+    return seed, s.astype(np.float64), s2.astype(np.float64), c.astype(np.int64), st
+
+
+def main():
+    with mp.Pool(min(len(SEEDS), os.cpu_count() or 1)) as pool:
+        parts = pool.map(one_seed, SEEDS)
+    s = sum(p[1] for p in parts)
+    s2 = sum(p[2] for p in parts)
+    c = sum(p[3] for p in parts)
+    segments = sum(p[4]["segments"] for p in parts)
+    contributing = sum(p[4]["contributing"] for p in parts)
+    out = os.path.join(HERE, "tor_reference_stream_128x128.npz")
+    np.savez_compressed(out, sum=s.astype(np.float32), sum2=s2.astype(np.float32), count=c.astype(np.int32),
+                        width=W, height=H, mrr=MRR, seeds=np.array(SEEDS), passes_per_seed=PASSES,
+                        segments=segments, contributing=contributing)
+    print(f"wrote {out}: {os.path.getsize(out)} bytes, {contributing} contributing of {W * H * PASSES * len(SEEDS)} samples, "
+          f"{segments} segments, lit pixels {(c > 0).mean():.3f}, mean count {c.mean():.1f}")
+
+
+if __name__ == "__main__":
+    main()

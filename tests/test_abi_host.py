@@ -28,12 +28,13 @@ def test_header_symbols_are_exported():
     assert declared == set(pt.ABI_SYMBOLS)
     for name in declared:
         assert getattr(pt.lib(), name) is not None
-    assert pt.lib().pt_abi_version() == 1
+    assert pt.lib().pt_abi_version() == 2 == pt.PT_ABI_VERSION
+    assert not hasattr(pt.lib(), "pt_test_set_mutation")      # the test hooks exist only in the test builds
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(pt.RenderParams) == 40
-    assert C.sizeof(pt.RenderStats) == 80
+    assert C.sizeof(pt.RenderParams) == 44
+    assert C.sizeof(pt.RenderStats) == 96
 
 
 def test_loader_matches_oracle_bit_for_bit(models_dir, oracle_scene):

@@ -112,10 +112,14 @@ def test_degenerate_and_tiny_triangles_are_always_kept(tmp_path):
     assert sorted(lay) == [2] and np.isfinite(t["spheres"][lay[2][1][-1]][3])
 
 
-def test_light_as_its_own_cluster_without_absorption(models_dir, monkeypatch):
-    """PT_NO_ABSORB=1 (a tuning knob of the table builder) restores the four runs of the file order."""
-    monkeypatch.setenv("PT_NO_ABSORB", "1")
-    t = pt.Scene.load_obj(models_dir, "Tor.obj", device=-1).cull_tables()
+def test_light_as_its_own_cluster_without_absorption(models_dir):
+    """The test build's `no_absorb` hook (a tuning knob of the table builder) restores the four runs of the file order."""
+    H = pt.load_library(pt.TESTHOOKS_LIB_PATH)
+    H.pt_test_set_mutation(b"no_absorb", 1.0)
+    try:
+        t = pt.Scene.load_obj(models_dir, "Tor.obj", device=-1, library=H).cull_tables()
+    finally:
+        H.pt_test_set_mutation(b"reset", 0.0)
     assert list(t["first_tri"]) == [0, 256, 258, 260] and list(t["n_tri"]) == [256, 2, 2, 10]
     assert list(t["kind"]) == [0, 1, 0, 1] and list(t["n_levels"][[0, 2]]) == [3, 1] and t["n_large"] == 12
 

@@ -1,0 +1,160 @@
+"""BASELINE.json configurations the round-1 suite did not reach, and every kernel instantiation against the oracle.
+
+configs[2]  Tor.obj 1920x1080 x 1024 spp: pass indices >= 64, long chunk schedules, 1024-term float sums.  The oracle
+            renders a small frame with all 1024 passes bit for bit; the full-size frame is checked through properties.
+configs[3]  Tor.obj 3840x2160 x 256 spp: a 3840-wide frame (global pixel indices above 2^22, 129 600 tiles).  Sampled
+            row pairs of a reduced-spp frame against the oracle, properties of the full frame.
+integrate_kernel<SKY,BIG,STATS>: all eight instantiations render oracle-identical frames.
+"""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pt = importlib.import_module("path-tracing_amd")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _digest(s, s2, c):
+    return hashlib.sha256(s.tobytes() + s2.tobytes() + c.tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def tor(models_dir):
+    assert pt.device_count() >= 1, "no HIP device: the integrator has no CPU fallback"
+    return pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+
+
+# ---- configs[2]: 1024 passes -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("error", [-1.0, 0.001])
+def test_1024_passes_bit_exact(tor, oracle_scene, error):
+    W, H, spp, mrr = 64, 48, 1024, 8
+    s, s2, c, st = tor.render_host(W, H, spp, mrr, error=error)
+    rs, rs2, rc, rst = O.render(oracle_scene, W, H, spp, mrr, error=error)
+    assert st["samples_traced"] == rst["samples_traced"] and st["segments"] == rst["segments"]
+    assert st["contributing"] == rst["contributing"] and st["misses"] == rst["misses"]
+    if error < 0:
+        assert st["samples_traced"] == W * H * spp
+    else:
+        assert st["samples_traced"] < 0.9 * W * H * spp          # the adaptive skip really fired (main.cpp:118-125)
+    assert np.array_equal(c, rc)
+    assert np.array_equal(_bits(s), _bits(rs)) and np.array_equal(_bits(s2), _bits(rs2))
+    # the statistics-free instantiation (the one bench.py times) on the same long pass range
+    q = tor.render_host(W, H, spp, mrr, error=error, want_stats=False)
+    assert np.array_equal(_bits(q[0]), _bits(rs)) and np.array_equal(_bits(q[1]), _bits(rs2)) and np.array_equal(q[2], rc)
+
+
+def test_1024_passes_pass_window_late_in_the_frame(tor, oracle_scene):
+    """Passes [960, 1024) alone, added to the oracle's accumulators of passes [0, 960): pass indices far above 64 enter
+    the RNG counter and the adaptive test sees sums of 960 terms."""
+    W, H, mrr = 48, 32, 8
+    acc = O.render(oracle_scene, W, H, 960, mrr, error=0.001)[:3]
+    ref = O.render(oracle_scene, W, H, 64, mrr, error=0.001, pass_begin=960, accum=tuple(a.copy() for a in acc))[:3]
+    got = tor.render_host(W, H, 64, mrr, error=0.001, pass_begin=960, accum=tuple(a.copy() for a in acc))[:3]
+    assert np.array_equal(got[2], ref[2])
+    assert np.array_equal(_bits(got[0]), _bits(ref[0])) and np.array_equal(_bits(got[1]), _bits(ref[1]))
+
+
+def test_config2_full_size_properties(tor):
+    W, H, spp, mrr = 1920, 1080, 1024, 8
+    s, s2, c, st = tor.render_host(W, H, spp, mrr, error=-1.0)
+    assert st["samples_traced"] == W * H * spp
+    assert 7.5 * st["samples_traced"] < st["segments"] <= mrr * st["samples_traced"]
+    assert st["contributing"] == int(c.sum(dtype=np.int64))
+    assert 0.005 < st["contributing"] / st["samples_traced"] < 0.02
+    assert (s >= 0).all() and (s2 <= s + 1e-2).all()                  # every contribution is <= 1 per channel
+    assert int(c.max()) <= spp
+    d = _digest(s, s2, c)
+    acc = None
+    for p0, n in [(0, 100), (100, 900), (1000, 24)]:                   # the same frame in three pass slices
+        acc = tor.render_host(W, H, n, mrr, error=-1.0, pass_begin=p0, accum=acc, want_stats=False)[:3]
+    assert _digest(*acc) == d
+
+
+# ---- configs[3]: the 3840 x 2160 frame ---------------------------------------------------------------------------
+def test_config3_sampled_rows_match_the_oracle(tor, oracle_scene):
+    W, H, spp, mrr = 3840, 2160, 8, 8
+    s, s2, c, st = tor.render_host(W, H, spp, mrr, error=-1.0)
+    assert st["samples_traced"] == W * H * spp
+    for r0 in (0, 822, 1079, 2158):          # top edge, torus, the seam of a two-band split, bottom edge (gpix > 2^23)
+        rs, rs2, rc, _ = O.render(oracle_scene, W, H, spp, mrr, rows=(r0, r0 + 2), error=-1.0)
+        sl = slice(r0 * W, (r0 + 2) * W)
+        assert np.array_equal(c[sl], rc)
+        assert np.array_equal(_bits(s[sl]), _bits(rs)) and np.array_equal(_bits(s2[sl]), _bits(rs2))
+
+
+def test_config3_full_size_properties(tor):
+    W, H, spp, mrr = 3840, 2160, 256, 8
+    s, s2, c, st = tor.render_host(W, H, spp, mrr, error=-1.0)
+    assert st["samples_traced"] == W * H * spp == 2123366400
+    assert st["contributing"] == int(c.sum(dtype=np.int64))
+    assert 0.005 < st["contributing"] / st["samples_traced"] < 0.02
+    d = _digest(s, s2, c)
+    # eight row bands of 270 rows (the 8-GPU split of configs[3]) assemble to the same frame
+    parts = [tor.render_host(W, H, spp, mrr, error=-1.0, rows=(270 * k, 270 * (k + 1)), want_stats=False)[:3] for k in range(8)]
+    assert _digest(*(np.concatenate([p[k] for p in parts]) for k in range(3))) == d
+
+
+# ---- every instantiation of integrate_kernel<SKY, BIG, STATS> ----------------------------------------------------
+def _replica(tmp, instances):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_replicated_scene as M
+    d = str(tmp) + "/"
+    name = f"TorX{instances}.obj"
+    n = M.generate(os.path.join(ROOT, "models"), d, name, instances)
+    return d, name, n
+
+
+def _write_sky(path, w, h, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    bgr = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), rng.integers(0, 256, (h, w))], -1).astype(np.uint8)
+    O.write_bmp(path, bgr)
+
+
+@pytest.mark.parametrize("sky", [False, True], ids=["nosky", "sky"])
+@pytest.mark.parametrize("big", [False, True], ids=["small", "big"])
+def test_all_instantiations_match_the_oracle(tmp_path, models_dir, sky, big):
+    d = str(tmp_path) + "/"
+    if big:
+        d, name, n = _replica(tmp_path, 9)            # 9 x 256 + 14 = 2318 triangles: above the deep-queue threshold
+        assert n > 2048
+    else:
+        name = "Tor.obj"
+        for f in ("Tor.obj", "Tor.mtl"):
+            open(d + f, "w").write(open(models_dir + f).read())
+    if sky:
+        # drop the back wall so that rays can reach the sky: keep every face but the last four of the file
+        lines = open(d + name).read().split("\n")
+        faces = [i for i, l in enumerate(lines) if l.startswith("f ")]
+        for i in faces[-4:]:
+            lines[i] = ""
+        open(d + name, "w").write("\n".join(lines))
+        _write_sky(d + "sky.bmp", 31, 17, seed=5)
+    g = pt.Scene.load_obj(d, name, device=0)
+    o = O.Scene.load(d, name)
+    if sky:
+        g.set_skybox(d + "sky.bmp")
+        o.set_skybox(d + "sky.bmp")
+    W, H, spp, mrr = 56, 40, 5, 8
+    for err in (-1.0, 0.01):
+        rs, rs2, rc, rst = O.render(o, W, H, spp + 14, mrr, error=err)
+        if sky:
+            assert rst["misses"] > 100
+        for want_stats in (True, False):             # STATS and statistics-free instantiations
+            s, s2, c, st = g.render_host(W, H, spp + 14, mrr, error=err, want_stats=want_stats)
+            assert np.array_equal(c, rc), (sky, big, want_stats, err)
+            assert np.array_equal(_bits(s), _bits(rs)) and np.array_equal(_bits(s2), _bits(rs2)), (sky, big, want_stats, err)
+            if want_stats:
+                assert st["segments"] == rst["segments"] and st["misses"] == rst["misses"]
+                assert st["n_triangles"] == o.n_tri

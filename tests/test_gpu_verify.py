@@ -1,0 +1,87 @@
+"""Every segment of a full frame against the reference's all-triangles loop, on the device.
+
+libpt_verify.so is the product library compiled with -DPT_VERIFY_BRUTE: after the culled closest-hit search of every
+path segment, the same lane runs Scene::TraceRay's loop as written (scene.cpp:116-120: every triangle, in index order,
+through Triangle::Intersect) for its own ray and the two (distance bits, triangle index) results are compared.  That
+turns "sampled rows against the CPU oracle" into EVERY segment of the frame -- about 10^9 at BASELINE configs[1] --
+without needing the CPU.  The frame itself must be the shipped library's frame bit for bit (same digest), so what is
+verified is the shipped search, not a variant of it.
+"""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pt = importlib.import_module("path-tracing_amd")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def vlib():
+    assert pt.device_count() >= 1, "no HIP device: the integrator has no CPU fallback"
+    L = pt.load_library(pt.VERIFY_LIB_PATH)
+    L.pt_test_set_mutation(b"reset", 0.0)
+    yield L
+    L.pt_test_set_mutation(b"reset", 0.0)
+
+
+def _digest(s, s2, c):
+    return hashlib.sha256(s.tobytes() + s2.tobytes() + c.tobytes()).hexdigest()
+
+
+def _replica(tmp, instances):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_replicated_scene as M
+    d = str(tmp) + "/"
+    name = f"TorX{instances}.obj"
+    M.generate(os.path.join(ROOT, "models"), d, name, instances)
+    return d, name
+
+
+def test_every_segment_of_config1(models_dir, vlib):
+    """BASELINE configs[1], the whole frame: 1920 x 1080 x 64 spp x MRR 8, about 1.05e9 segments x 270 triangles."""
+    W, H, spp, mrr = 1920, 1080, 64, 8
+    v = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=vlib)
+    s, s2, c, st = v.render_host(W, H, spp, mrr, error=-1.0)
+    assert st["verify_checked"] == st["segments"] > 7.5 * W * H * spp
+    assert st["verify_mismatches"] == 0
+    g = pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+    q = g.render_host(W, H, spp, mrr, error=-1.0, want_stats=False)
+    assert _digest(*q[:3]) == _digest(s, s2, c)            # the shipped library renders exactly the verified frame
+    assert g.render_host(16, 16, 1, 2)[3]["verify_checked"] == 0   # and carries no verification code
+
+
+def test_every_segment_with_adaptive_sampling_and_other_eps(models_dir, vlib):
+    v = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=vlib)
+    for eps, err in ((1e-4, 0.001), (1e-3, -1.0), (1e-5, -1.0)):
+        st = v.render_host(960, 540, 32, 8, error=err, eps=eps)[3]
+        assert st["verify_checked"] == st["segments"] > 0 and st["verify_mismatches"] == 0, (eps, err, st)
+
+
+@pytest.mark.parametrize("instances,W,H,spp", [(64, 1920, 1080, 4), (195, 960, 540, 2)])
+def test_every_segment_of_the_replicated_scene(tmp_path, vlib, instances, W, H, spp):
+    """BASELINE configs[4] geometry (x64 -> 16 398 triangles, x195 -> 49 934): the deep-queue kernel with the pair
+    pre-filter, every segment against all triangles."""
+    d, name = _replica(tmp_path, instances)
+    v = pt.Scene.load_obj(d, name, device=0, library=vlib)
+    s, s2, c, st = v.render_host(W, H, spp, 8, error=-1.0)
+    assert st["verify_checked"] == st["segments"] > 7 * W * H * spp
+    assert st["verify_mismatches"] == 0
+    g = pt.Scene.load_obj(d, name, device=0)
+    q = g.render_host(W, H, spp, 8, error=-1.0, want_stats=False)
+    assert _digest(*q[:3]) == _digest(s, s2, c)
+
+
+def test_the_check_notices_a_cull_that_is_too_tight(models_dir, vlib):
+    """Negative control: with every sphere's r^2 halved the culled search loses real hits and the comparison counts them."""
+    vlib.pt_test_set_mutation(b"sphere_r2", 0.5)
+    try:
+        v = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=vlib)
+        st = v.render_host(480, 270, 8, 8, error=-1.0)[3]
+    finally:
+        vlib.pt_test_set_mutation(b"reset", 0.0)
+    assert st["verify_checked"] == st["segments"] and st["verify_mismatches"] > 100

@@ -5,8 +5,14 @@
 // and write "<date>  <ms>   <n> of <rpp>  max_disp .. min_disp .. aver_disp ...bmp" plus "../result.bmp".
 // The passes themselves run on the GPU through the C ABI; nothing here computes radiance.
 //
+// The accumulators stay on the device for the whole frame (pt_session): they cross PCIe only when a preview or the final
+// image needs them.  With -TL the pass slices are kept to about 75 ms (from the measured time per pass, never less than
+// one pass), so the time limit is checked at the reference's granularity -- before a pass starts (main.cpp:111-114) --
+// whatever -UPDATE is.
+//
 // Extra flags (not in the reference): -OUT <file> writes only that file instead of the two reference outputs,
-// -DEVICE <n> selects the HIP device, -QUIET 1 drops the per-pass lines.
+// -DEVICE <n> selects the HIP device, -QUIET 1 drops the per-pass lines, -TIMING 1 prints one JSON line with the
+// seconds spent in each phase (HIP start-up, load, render, read-back, resolve, BMP write) on stderr.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -30,7 +36,7 @@ struct Options {   // defaults: config.h:16-29
     std::string model_path = "../models/", model_name = "Tor.obj", skybox;
     int seed = 42, time_limit = 0;
     std::string out;
-    int device = 0, quiet = 0;
+    int device = 0, quiet = 0, timing = 0;
 };
 
 long long now_ms() {
@@ -60,6 +66,7 @@ void parse(int argc, char **argv, Options &o) {   // pairs `flag value` from arg
         if (f == "-OUT") o.out = v;
         if (f == "-DEVICE") o.device = std::atoi(v);
         if (f == "-QUIET") o.quiet = std::atoi(v);
+        if (f == "-TIMING") o.timing = std::atoi(v);
     }
 }
 
@@ -80,46 +87,85 @@ int main(int argc, char **argv) {
     }
     const unsigned seed = o.seed < 0 ? static_cast<unsigned>(std::time(nullptr)) : static_cast<unsigned>(o.seed);   // config.h:101-104
 
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const clk::time_point t_begin = clk::now();
+    if (pt_device_count() < 1) {   // first HIP call: runtime start-up
+        std::cerr << "pt_render: no HIP device (the integrator has no CPU fallback)" << std::endl;
+        return 1;
+    }
+    const clk::time_point t_hip = clk::now();
     pt_scene *scene = nullptr;
     if (pt_scene_load_obj(o.model_path.c_str(), o.model_name.c_str(), o.device, &scene) != PT_OK) return die("pt_render");
     if (!o.skybox.empty() && pt_scene_set_skybox_bmp(scene, o.skybox.c_str()) != PT_OK) return die("pt_render");   // scene.cpp:20-22
+    const clk::time_point t_load = clk::now();
 
     const size_t px = static_cast<size_t>(o.width) * o.height;
-    std::vector<float> sum(3 * px, 0.0f), sum2(3 * px, 0.0f);
-    std::vector<int32_t> count(px, 0);
+    std::vector<float> sum(3 * px), sum2(3 * px);
+    std::vector<int32_t> count(px);
     std::vector<uint8_t> bgr(3 * px);
     float disp[3] = {0, INFINITY, 0};
+    double read_s = 0, preview_s = 0;
 
+    pt_session *session = nullptr;
+    if (pt_session_create(scene, o.width, o.height, 0, o.height, &session) != PT_OK) return die("pt_render");
     pt_render_params rp;
     std::memset(&rp, 0, sizeof rp);
     rp.width = o.width; rp.height = o.height; rp.row_begin = 0; rp.row_end = o.height;
     rp.max_ray_reflections = o.max_ray_reflections;
     rp.eps = o.eps; rp.error = o.error; rp.seed = seed;
+    auto read_back = [&]() {
+        const clk::time_point a = clk::now();
+        const int rc = pt_session_read(session, sum.data(), sum2.data(), count.data());
+        read_s += secs(a, clk::now());
+        return rc;
+    };
 
     // Pass slices end exactly where the reference writes a preview (after every pass p with p % update == 0,
-    // main.cpp:144-158) so that previews and the -TL check (main.cpp:111-114) happen between GPU calls.
+    // main.cpp:144-158) so that previews happen between GPU calls; with a time limit they are also kept short.
     int rays_count = 0;
+    double ms_per_pass = 0;   // measured on the previous slice (0 = not yet known)
     while (rays_count < o.rays_per_pixel) {
-        if (o.time_limit != 0 && now_ms() - start_time >= 1000LL * o.time_limit) break;
+        const long long elapsed_ms = now_ms() - start_time;
+        if (o.time_limit != 0 && elapsed_ms >= 1000LL * o.time_limit) break;   // main.cpp:111-114
         int slice_end = o.rays_per_pixel;
         if (o.update != 0) {
             const int next_preview = (rays_count % o.update == 0) ? rays_count : (rays_count / o.update + 1) * o.update;
             slice_end = std::min(o.rays_per_pixel, next_preview + 1);
         }
+        if (o.time_limit != 0) {
+            // the reference would start every pass that begins before the deadline: run as many as are expected to,
+            // at most ~75 ms worth, at least one
+            int n = 1;
+            if (ms_per_pass > 0) {
+                const double left_ms = 1000.0 * o.time_limit - static_cast<double>(elapsed_ms);
+                n = static_cast<int>(std::min(75.0, left_ms) / ms_per_pass);
+                n = std::max(1, n);
+            }
+            slice_end = std::min(slice_end, rays_count + n);
+        }
         rp.pass_begin = rays_count;
         rp.pass_count = slice_end - rays_count;
-        if (pt_render_host(scene, &rp, sum.data(), sum2.data(), count.data(), nullptr) != PT_OK) return die("pt_render");
+        pt_render_stats st;
+        const clk::time_point a = clk::now();
+        if (pt_session_render(session, &rp, o.time_limit != 0 ? &st : nullptr) != PT_OK) return die("pt_render");
+        if (o.time_limit != 0) ms_per_pass = 1e3 * secs(a, clk::now()) / rp.pass_count;   // the call waited for the kernel
         for (int p = rays_count; p < slice_end; ++p) {
             if (o.update != 0 && p % o.update == 0) {
+                const clk::time_point b = clk::now();
+                if (read_back() != PT_OK) return die("pt_render");
                 pt_resolve(o.width, o.height, sum.data(), sum2.data(), count.data(), o.gamma_correction, bgr.data(), nullptr);
                 if (o.out.empty() && pt_write_bmp("../result.bmp", o.width, o.height, bgr.data()) != PT_OK)
                     std::cerr << pt_last_error() << std::endl;   // the reference's save_image only prints, too
                 std::cerr << "Image update" << std::endl;
+                preview_s += secs(b, clk::now());
             }
             if (!o.quiet) std::cerr << p + 1 << " rays per pixel were sent" << std::endl;
         }
         rays_count = slice_end;
     }
+    if (read_back() != PT_OK) return die("pt_render");   // waits for the last slice
+    const clk::time_point t_render = clk::now();
 
     if (o.gauss || o.median) {   // main.cpp:187-201: filters act on the tonemapped float image, then set_pixel
         std::vector<float> rgb(3 * px);
@@ -129,6 +175,7 @@ int main(int argc, char **argv) {
     } else {
         pt_resolve(o.width, o.height, sum.data(), sum2.data(), count.data(), o.gamma_correction, bgr.data(), disp);
     }
+    const clk::time_point t_resolve = clk::now();
     const long long end_time = now_ms();
     const std::time_t t = std::time(nullptr);
     const std::tm *now = std::localtime(&t);
@@ -145,6 +192,14 @@ int main(int argc, char **argv) {
         if (pt_write_bmp("../result.bmp", o.width, o.height, bgr.data()) != PT_OK) rc = die("pt_render");
     }
     std::cout << name << std::endl;
+    if (o.timing) {
+        const clk::time_point t_end = clk::now();
+        std::fprintf(stderr, "{\"hip_startup_s\": %.4f, \"load_s\": %.4f, \"render_s\": %.4f, \"read_back_s\": %.4f, \"previews_s\": %.4f, "
+                             "\"resolve_s\": %.4f, \"bmp_write_s\": %.4f, \"total_s\": %.4f}\n",
+                     secs(t_begin, t_hip), secs(t_hip, t_load), secs(t_load, t_render) - read_s - preview_s, read_s, preview_s,
+                     secs(t_render, t_resolve), secs(t_resolve, t_end), secs(t_begin, t_end));
+    }
+    pt_session_destroy(session);
     pt_scene_destroy(scene);
     return rc;
 }
