@@ -30,7 +30,7 @@ TESTHOOKS_LIB_PATH = os.path.join(_HERE, "lib", "libpt_testhooks.so")
 ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
                "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_trace_rays_host",
                "pt_session_create", "pt_session_render", "pt_session_read", "pt_session_clear", "pt_session_destroy",
-               "pt_scene_cull_tables", "pt_scene_set_skybox_bmp", "pt_resolve", "pt_resolve_float",
+               "pt_scene_cull_tables", "pt_scene_cull_layout", "pt_scene_set_skybox_bmp", "pt_resolve", "pt_resolve_float",
                "pt_post_filter_host", "pt_quantize",
                "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
 
@@ -117,6 +117,7 @@ def load_library(path):
     L.pt_session_destroy.restype = None
     L.pt_trace_rays_host.argtypes = [vp, C.c_int32, fp, fp, C.c_float, ip, fp]
     L.pt_scene_cull_tables.argtypes = [vp, C.c_float, ip, fp, fp, fp, fp]
+    L.pt_scene_cull_layout.argtypes = [vp, C.c_float, ip, ip, vp]
     L.pt_scene_set_skybox_bmp.argtypes = [vp, C.c_char_p]
     L.pt_resolve.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, C.POINTER(C.c_uint8), fp]
     L.pt_resolve_float.argtypes = [C.c_int32, C.c_int32, fp, fp, ip, C.c_float, fp, fp]
@@ -227,6 +228,15 @@ class Scene:
                 "level_off": np.concatenate([np.zeros((len(cl), 1), int), meta[:, 5:12].astype(int)], 1),
                 "spheres": sp, "bary": ba,
                 "constants": dict(zip(["k1", "k2", "a_max", "m0", "t_guard"], k.tolist())), "n_large": int(counts[3])}
+
+    def cull_layout(self, eps=1e-4):
+        """Slot order of the hierarchy: dict with slot_triangle (original index per slot, -1 = padding), node counts."""
+        counts = np.zeros(4, np.int32)
+        _check(self._L.pt_scene_cull_layout(self._h, eps, _ip(counts), None, None), self._L)
+        st = np.zeros(counts[0], np.int32)
+        nodes = np.zeros((counts[1], 64), np.uint8)
+        _check(self._L.pt_scene_cull_layout(self._h, eps, _ip(counts), _ip(st), nodes.ctypes.data_as(C.c_void_p)), self._L)
+        return {"slot_triangle": st, "bvh": nodes, "bvh_first_leaf": int(counts[2]), "clusters": int(counts[3])}
 
     def trace_rays(self, origins, directions, eps=1e-4):
         """Closest hit per ray (scene.cpp:114-120).  directions must be unit length (normalised as ray.h:23 does)."""

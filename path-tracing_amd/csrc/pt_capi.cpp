@@ -28,6 +28,8 @@ struct DeviceCull {
     pt::SphereRec *spheres = nullptr;
     pt::CullRec *bary = nullptr;
     pt::CullRec *bary_all = nullptr;
+    pt::ExactRec *exact_slot = nullptr;
+    pt::BvhNode *bvh = nullptr;
 };
 
 struct pt_scene {
@@ -138,6 +140,12 @@ int ensure_cull(pt_scene *s, float eps) {
         c.bary_all = nullptr;
     }
     if (!c.host.bary_all.empty() && (rc = upload_vec(c.host.bary_all, &c.bary_all)) != PT_OK) return rc;
+    if ((rc = upload_vec(c.host.exact_slot, &c.exact_slot)) != PT_OK) return rc;
+    if (c.bvh) {
+        (void)hipFree(c.bvh);
+        c.bvh = nullptr;
+    }
+    if (!c.host.bvh.empty() && (rc = upload_vec(c.host.bvh, &c.bvh)) != PT_OK) return rc;
     c.eps = eps;
     c.valid = true;
     return PT_OK;
@@ -149,8 +157,8 @@ struct SceneDeleter {
 using ScenePtr = std::unique_ptr<pt_scene, SceneDeleter>;   // frees host and device side on every early return / exception
 
 int finish_scene(ScenePtr s, int device, pt_scene **out) {
-    if (s->host.n_tri() >= (1 << 24))   // work items carry the triangle index in 24 bits
-        return fail(PT_ERR_INVALID_ARGUMENT, "more than 16 777 215 triangles");
+    if (s->host.n_tri() >= (1 << 23))   // work items carry a slot index in 24 bits, and the box tree pads its leaves to 8 slots
+        return fail(PT_ERR_INVALID_ARGUMENT, "more than 8 388 607 triangles");
     for (int m : s->host.tri_mat)
         if (m < 0 || m >= s->host.n_mat()) return fail(PT_ERR_INVALID_ARGUMENT, "triangle refers to material " + std::to_string(m));
     pt::build_device_tables(s->host, s->tables);
@@ -172,6 +180,11 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.bary_all = scene->cull.bary_all;
     a.a_max_all = ca.a_max; a.m0_all = ca.m0; a.t_guard_all = ca.t_guard;
     a.exact = scene->d_exact;
+    a.exact_slot = scene->cull.exact_slot;
+    a.bvh = scene->cull.bvh;
+    a.bvh_leaf0 = scene->cull.host.bvh_leaf0;
+    a.n_bvh = static_cast<uint32_t>(scene->cull.host.bvh.size());
+    a.bvh_err = scene->cull.host.bvh_err;
     a.mats = scene->d_mats;
     a.sky = scene->d_sky;
     a.sky_w = scene->sky_w;
@@ -337,6 +350,8 @@ void pt_scene_destroy(pt_scene *s) {
         if (s->cull.spheres) (void)hipFree(s->cull.spheres);
         if (s->cull.bary) (void)hipFree(s->cull.bary);
         if (s->cull.bary_all) (void)hipFree(s->cull.bary_all);
+        if (s->cull.exact_slot) (void)hipFree(s->cull.exact_slot);
+        if (s->cull.bvh) (void)hipFree(s->cull.bvh);
         if (s->d_exact) (void)hipFree(s->d_exact);
         if (s->d_mats) (void)hipFree(s->d_mats);
         if (s->d_stats) (void)hipFree(s->d_stats);
@@ -585,6 +600,20 @@ static int scene_cull_tables_impl(pt_scene *scene, float eps, int32_t *counts, f
     return PT_OK;
 }
 
+static int scene_cull_layout_impl(pt_scene *scene, float eps, int32_t *counts, int32_t *slot_triangle, void *bvh_nodes) {
+    if (!scene || !counts) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    pt::CullTables t;
+    pt::build_cull_tables(scene->host, eps, t);
+    counts[0] = static_cast<int32_t>(t.slot_tri.size());
+    counts[1] = static_cast<int32_t>(t.bvh.size());
+    counts[2] = static_cast<int32_t>(t.bvh_leaf0);
+    counts[3] = static_cast<int32_t>(t.clusters.size());
+    if (slot_triangle)
+        for (size_t k = 0; k < t.slot_tri.size(); ++k) slot_triangle[k] = t.slot_tri[k] == pt::kNoTriangle ? -1 : static_cast<int32_t>(t.slot_tri[k]);
+    if (bvh_nodes && !t.bvh.empty()) std::memcpy(bvh_nodes, t.bvh.data(), t.bvh.size() * sizeof(pt::BvhNode));
+    return PT_OK;
+}
+
 int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
                uint8_t *bgr, float *dispersion) {
     if (width <= 0 || height <= 0 || !sum || !sum2 || !count || !bgr)
@@ -803,6 +832,10 @@ int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clu
     return guarded([&] { return scene_cull_tables_impl(scene, eps, counts, clusters, spheres, bary, constants); });
 }
 
+int pt_scene_cull_layout(pt_scene *scene, float eps, int32_t *counts, int32_t *slot_triangle, void *bvh_nodes) {
+    return guarded([&] { return scene_cull_layout_impl(scene, eps, counts, slot_triangle, bvh_nodes); });
+}
+
 int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median) {
     return guarded([&] { return post_filter_host_impl(device, width, height, rgb, gauss, median); });
 }
@@ -821,6 +854,8 @@ int pt_test_set_mutation(const char *family, double value) {
     else if (f == "k12") m.k12 = value;
     else if (f == "a_max") m.a_max = value;
     else if (f == "quad_slack") m.quad_slack = value;
+    else if (f == "box") m.box = value;
+    else if (f == "box_err") m.box_err = value;
     else if (f == "no_absorb") m.no_absorb = value != 0;
     else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);
     else return fail(PT_ERR_INVALID_ARGUMENT, "unknown mutation family " + f);

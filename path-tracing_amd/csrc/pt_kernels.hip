@@ -227,20 +227,14 @@ __device__ __forceinline__ float area2_of(float ax, float ay, float az, float bx
     const float cz = ax * by - bx * ay;
     return cx * cx + cy * cy + cz * cz;
 }
-// IEEE sqrt / reciprocal with the lean sequences of pt_fastfp.hpp when every active lane's argument is in their
-// (exhaustively verified) range, the compiler's full expansion otherwise -- the result is the same bits either way.
-__device__ __forceinline__ float sqrt_rn(float x) {
-    if (__all(fast_fp_ok(x))) return sqrt_rn_normal(x);
-    return __builtin_sqrtf(x);
-}
-
 // Stages B-D of Triangle::Intersect for one (ray, triangle) pair, without the running `distance`:
 // returns new_distance if the point passes the area tests, -inf otherwise (then stage A rejects it: -inf < eps).
-__device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, const Ray &q, float eps) {
+__device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, const Ray &q, float eps, uint32_t &orig) {
     const float4 r0 = reinterpret_cast<const float4 *>(rec)[0];   // plane
     const float4 r1 = reinterpret_cast<const float4 *>(rec)[1];   // v0, square
     const float4 r2 = reinterpret_cast<const float4 *>(rec)[2];   // v1, material
-    const float4 r3 = reinterpret_cast<const float4 *>(rec)[3];   // v2
+    const float4 r3 = reinterpret_cast<const float4 *>(rec)[3];   // v2, original triangle index
+    orig = __float_as_uint(r3.w);
     const float signed_dist = q.dx * r0.x + q.dy * r0.y + q.dz * r0.z;
     const float nd = -(q.ox * r0.x + q.oy * r0.y + q.oz * r0.z + r0.w) / signed_dist;
     const float px = q.ox + q.dx * nd, py = q.oy + q.dy * nd, pz = q.oz + q.dz * nd;
@@ -305,7 +299,7 @@ struct WaveLds {
     unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
     float ray[6][64];              // this segment's rays, readable by every lane
     uint32_t nodes[kNodeStack + 64];// LIFO of tree nodes to expand: lane << 26 | level << 23 | node index within its level
-    uint32_t pairs[kPairQueue];    // (ray, triangle) work items: triangle index | lane << 24
+    uint32_t pairs[kPairQueue];    // (ray, triangle) work items: slot index | lane << 24
     uint32_t level_off[kMaxLevels];// sphere offset of each level of the cluster being walked
     uint32_t level_cnt[kMaxLevels];// number of real nodes of each level
     float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
@@ -367,6 +361,45 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Box tree of big scenes (pt_scene.hpp: BvhNode): which of a node's (up to 8) children can hold a hit of ray r that
+// beats t_best?  Slab test against the 8-bit child boxes, dequantised on the fly: along axis x the planes of child c are
+// t = (org.x + q step - o.x) / d.x = A q + B with A = step / d.x, B = (org.x - o.x) / d.x, one fma per plane.
+// CONSERVATIVE: every computed t is within E = err (|B| + 255 |A|) of its exact value (rcp 1 ulp, one product, one fma:
+// < 3e-7 relative to the operands' magnitudes; err = 4e-7), the boxes were rounded outward on the host, and a child is
+// dropped only if its interval misses [0, t_best] by more than 2E.  A zero direction component is replaced by 1e-30 of
+// the same sign: the ray then misses a slab it starts outside of by an astronomically large t and spans one it starts in.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return static_cast<float>((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
+__device__ __forceinline__ float safe_rcp(float d) {
+    const float m = __builtin_fmaxf(__builtin_fabsf(d), 1.0e-30f);
+    return __builtin_amdgcn_rcpf(__builtin_copysignf(m, d));
+}
+__device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
+                                                      float t_best, float err) {
+    const float step = __uint_as_float((q0.w & 0xFFu) << 23);
+    const float ix = safe_rcp(r.dx), iy = safe_rcp(r.dy), iz = safe_rcp(r.dz);
+    const float ax = step * ix, ay = step * iy, az = step * iz;
+    const float bx = (__uint_as_float(q0.x) - r.ox) * ix, by = (__uint_as_float(q0.y) - r.oy) * iy, bz = (__uint_as_float(q0.z) - r.oz) * iz;
+    const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx), __builtin_fabsf(by)), __builtin_fabsf(bz));
+    const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ax), __builtin_fabsf(ay)), __builtin_fabsf(az));
+    const float e2 = 2.0f * err * __builtin_fmaf(255.0f, amax, bmax);
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = c & 3;
+        const bool up = c >= 4;
+        const float x0 = __builtin_fmaf(ax, byte_to_float(up ? q1.y : q1.x, k), bx), x1 = __builtin_fmaf(ax, byte_to_float(up ? q2.w : q2.z, k), bx);
+        const float y0 = __builtin_fmaf(ay, byte_to_float(up ? q1.w : q1.z, k), by), y1 = __builtin_fmaf(ay, byte_to_float(up ? q3.y : q3.x, k), by);
+        const float z0 = __builtin_fmaf(az, byte_to_float(up ? q2.y : q2.x, k), bz), z1 = __builtin_fmaf(az, byte_to_float(up ? q3.w : q3.z, k), bz);
+        const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
+        const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fminf(__builtin_fmaxf(z0, z1), t_best));
+        m |= !(t_in > t_out + e2) ? (1u << c) : 0u;   // a NaN keeps
+    }
+    return m;
+}
+
 // Scene::TraceRay's triangle loop exactly as the reference runs it (scene.cpp:116-120): every triangle, in index order,
 // through Triangle::Intersect for this lane's ray; returns the closest-hit key (~0 = miss).  Wave-uniform control flow.
 // Used for rays outside the envelope the culling margins were derived for (pt_trace_rays_host) and by the verification
@@ -374,7 +407,8 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
 __device__ __noinline__ unsigned long long brute_force_key(const RenderArgs &a, const Ray &q, float eps) {
     unsigned long long best = ~0ull;
     for (int i = 0; i < a.n_tri; ++i) {
-        const float nd = exact_inside(a.exact + i, q, eps);
+        uint32_t orig;
+        const float nd = exact_inside(a.exact + i, q, eps, orig);
         if (nd >= eps && nd < __builtin_inff()) {
             const unsigned long long k = (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | static_cast<uint32_t>(i);
             best = k < best ? k : best;
@@ -408,9 +442,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             Ray r;
             r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
             r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
-            const float nd = exact_inside(a.exact + tri, r, eps);   // -inf unless stages B-D pass
+            uint32_t orig;   // the pair names a SLOT; the closest-hit key carries the original triangle index (tie-break)
+            const float nd = exact_inside(a.exact_slot + tri, r, eps, orig);   // -inf unless stages B-D pass
             if (nd >= eps && nd < __builtin_inff())
-                atomicMin(&lds.best[src], (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | tri);
+                atomicMin(&lds.best[src], (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | orig);
         }
     };
     auto drain_pairs = [&](uint32_t keep_below) {
@@ -753,6 +788,84 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         }
     }
     PT_STAMP(st, 1);
+    if constexpr (Lds::kPrefilter) {
+        // ---- big scenes: ONE box tree over all small triangles, walked with the wave-wide LIFO of (ray, node) items.
+        // The large class above went first and is tested right away, so that lds.best already holds a hit (the wall behind
+        // everything, in a closed room) when the walk starts: a node whose box the ray enters beyond its best hit so far is
+        // dropped, and because pairs are tested as soon as 64 are waiting, closer hits keep shrinking the rest of the walk.
+        if (a.n_bvh > 0) {
+            flush_pending();
+            drain_pairs(0);
+            if (n_filtered > 0) {
+                const bool active = static_cast<uint32_t>(lane) < n_filtered;
+                exact_round(active ? lds.filtered[lane] : 0u, active, n_filtered);
+                n_filtered = 0;
+                wave_sync();
+            }
+            uint32_t n_nodes;
+            {
+                const unsigned long long vb = __ballot(valid);
+                if (valid) lds.nodes[lanes_below(vb)] = static_cast<uint32_t>(lane) << 26;   // the root, for every live ray
+                n_nodes = __builtin_popcountll(vb);
+                wave_sync();
+            }
+            while (n_nodes > 0) {
+                ++st.w_node_rounds;
+                const uint32_t cnt = min(64u, n_nodes);
+                uint32_t m8 = 0, src = 0, base = 0;
+                bool leaf = false;
+                if (static_cast<uint32_t>(lane) < cnt) {
+                    const uint32_t e = lds.nodes[n_nodes - 1 - lane];
+                    src = e >> 26;
+                    const uint32_t node = e & 0x3FFFFFFu;
+                    Ray r;
+                    r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
+                    r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
+                    const uint32_t bh = static_cast<uint32_t>(lds.best[src] >> 32);
+                    const float t_best = bh == 0xFFFFFFFFu ? __builtin_inff() : from_ordered_bits(bh);
+                    const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
+                    const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    m8 = box_children_kept(q0, q1, q2, q3, r, t_best, a.bvh_err);
+                    m8 &= (2u << ((q0.w >> 8) & 7u)) - 1u;   // children that exist
+                    leaf = node >= a.bvh_leaf0;
+                    base = leaf ? (node - a.bvh_leaf0) * kFan : (q0.w >> 11);
+                }
+                const uint32_t kids = __builtin_popcount(m8);
+                uint32_t keep = cnt;
+                const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = wave_sum(leaf ? 0u : kids, 4);
+                if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
+                if (!(n_pairs + tot_tri <= kPairQueue && n_nodes - cnt + tot_node <= kNodeStack)) {
+                    // Rare: not everything fits.  Commit the longest prefix of lanes (= the top of the stack) whose children do;
+                    // the top item always commits (its children are one level deeper; the 64 slots of slack absorb them).
+                    const uint32_t it = wave_inclusive_scan(leaf ? kids : 0u, lane), in = wave_inclusive_scan(leaf ? 0u : kids, lane);
+                    const bool fits = static_cast<uint32_t>(lane) < cnt && n_pairs + it <= kPairQueue &&
+                                      (n_nodes - (lane + 1)) + in <= kNodeStack;
+                    const unsigned long long fb = __ballot(fits);
+                    keep = (fb == ~0ull) ? 64u : static_cast<uint32_t>(__builtin_ctzll(~fb));
+                    if (keep == 0) keep = 1;
+                    ++st.w_partial;
+                    if (static_cast<uint32_t>(lane) >= keep) m8 = 0;
+                }
+                n_nodes -= keep;
+                wave_sync();
+                uint32_t nb = leaf ? 0u : m8;
+                while (__any(nb != 0)) {
+                    const bool has = nb != 0;
+                    const unsigned long long ball = __ballot(has);
+                    if (has) {
+                        const uint32_t c8 = __builtin_ctz(nb);
+                        nb &= nb - 1;
+                        lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (base + c8);
+                    }
+                    n_nodes += __builtin_popcountll(ball);
+                }
+                wave_sync();
+                push_pairs(leaf ? m8 : 0u, base, src);
+                if (n_pairs >= 64u) drain_pairs(63);
+            }
+            PT_STAMP(st, 2);
+        }
+    }
     flush_pending();
     drain_pairs(0);
     if constexpr (Lds::kPrefilter) {
@@ -1069,10 +1182,11 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
 }
 
 // Closest hit for caller-supplied rays (the intersection half of Scene::TraceRay, scene.cpp:114-120).
-__global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void trace_rays_kernel(const RenderArgs a, const float *__restrict__ origins,
+template <bool BIG>
+__global__ __launch_bounds__(kBlock, BIG ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void trace_rays_kernel(const RenderArgs a, const float *__restrict__ origins,
                                                                               const float *__restrict__ directions, int n_rays,
                                                                               int32_t *__restrict__ hit_index, float *__restrict__ hit_t) {
-    __shared__ WaveLds<SmallQueues> lds;
+    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;
     const int lane = threadIdx.x;
     const int i = blockIdx.x * kBlock + lane;
     const bool valid = i < n_rays;
@@ -1108,8 +1222,10 @@ hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, con
                              int32_t *d_hit_index, float *d_hit_t, hipStream_t stream) {
     if (n_rays <= 0) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((n_rays + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(kBlock), 0, stream, args, d_origins, d_directions, n_rays,
-                       d_hit_index, d_hit_t);
+    if (args.n_tri > kBigSceneTriangles)
+        hipLaunchKernelGGL(trace_rays_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, args, d_origins, d_directions, n_rays, d_hit_index, d_hit_t);
+    else
+        hipLaunchKernelGGL(trace_rays_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, args, d_origins, d_directions, n_rays, d_hit_index, d_hit_t);
     return hipGetLastError();
 }
 

@@ -16,7 +16,11 @@ struct RenderArgs {
     const CullRec *bary;
     const CullRec *bary_all;        // big scenes: one record per triangle for the pair pre-filter, else nullptr
     float a_max_all, m0_all, t_guard_all;
-    const ExactRec *exact;    // n_tri
+    const ExactRec *exact;    // n_tri records in the ORIGINAL triangle order: shading, the reference's all-triangles loop
+    const ExactRec *exact_slot;   // the same records in slot order, `orig` = original index: the exact test of (ray, slot) pairs
+    const BvhNode *bvh;       // big scenes: box tree over the small triangles, else nullptr
+    uint32_t bvh_leaf0, n_bvh;    // first leaf node, number of nodes
+    float bvh_err;            // relative rounding allowance of the slab arithmetic
     const MatRec *mats;
     const uint8_t *sky;       // skybox texels (B,G,R bytes, top-down rows) or nullptr
     int32_t sky_w, sky_h;

@@ -172,7 +172,7 @@ void build_device_tables(const HostScene &s, DeviceTables &out) {
         std::memcpy(e.v1, r + 7, 12);
         e.material = s.tri_mat[i];
         std::memcpy(e.v2, r + 10, 12);
-        e.pad = 0.0f;
+        e.orig = i;
     }
     out.mats.resize(s.n_mat());
     for (int m = 0; m < s.n_mat(); ++m) {   // Factory, material.h:58-106
@@ -279,6 +279,288 @@ void bounding_sphere(const std::vector<V3> &pts, V3 &c, double &rad) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------
+// Slot order: which triangles are culled how, and in what order the tables list them
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Centroid {
+    double c[3];
+};
+
+// Total order on triangles that depends on their GEOMETRY only (the file order enters last, for exact duplicates), so
+// that a shuffled OBJ gives the same hierarchy.
+struct GeoLess {
+    const HostScene *s;
+    const std::vector<Centroid> *cen;
+    int axis;
+    bool operator()(int a, int b) const {
+        for (int k = 0; k < 3; ++k) {
+            const double x = (*cen)[a].c[(axis + k) % 3], y = (*cen)[b].c[(axis + k) % 3];
+            if (x != y) return x < y;
+        }
+        const int m = std::memcmp(&s->tri[14 * static_cast<size_t>(a)], &s->tri[14 * static_cast<size_t>(b)], 14 * sizeof(float));
+        if (m != 0) return m < 0;
+        return a < b;
+    }
+};
+
+int longest_axis(const std::vector<int> &ids, size_t b, size_t e, const std::vector<Centroid> &cen) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = b; i < e; ++i)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], cen[ids[i]].c[k]);
+            hi[k] = std::max(hi[k], cen[ids[i]].c[k]);
+        }
+    int ax = 0;
+    for (int k = 1; k < 3; ++k)
+        if (hi[k] - lo[k] > hi[ax] - lo[ax]) ax = k;
+    return ax;
+}
+
+// Reorders ids[b, e) into `sizes.size()` consecutive groups of the given sizes, each spatially compact: recursive
+// bisection of the group list along the longest axis of the centroids.
+void partition_groups(std::vector<int> &ids, size_t b, const std::vector<size_t> &sizes, size_t g0, size_t g1, const HostScene &s,
+                      const std::vector<Centroid> &cen) {
+    if (g1 - g0 <= 1) return;
+    const size_t gm = g0 + (g1 - g0) / 2;
+    size_t left = 0, total = 0;
+    for (size_t g = g0; g < g1; ++g) {
+        if (g < gm) left += sizes[g];
+        total += sizes[g];
+    }
+    const GeoLess less{&s, &cen, longest_axis(ids, b, b + total, cen)};
+    std::nth_element(ids.begin() + b, ids.begin() + b + left, ids.begin() + b + total, less);
+    partition_groups(ids, b, sizes, g0, gm, s, cen);
+    partition_groups(ids, b + left, sizes, gm, g1, s, cen);
+}
+
+// Surface-area-heuristic version for the box tree of big scenes: splits ids[b, e) into k consecutive children of AT MOST
+// `cap` triangles each (sizes appended to `sizes`), by recursive bisection: each cut goes, along the best of the three
+// axes, where area(left) * n_left + area(right) * n_right of the triangles' bounding boxes is smallest among the
+// positions the capacities allow -- so children follow the objects of the scene (the gaps between them) instead of
+// cutting through them at equal counts.
+struct VBox {
+    double lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; } }
+    void add(const VBox &o) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); } }
+    double area() const {
+        const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x < 0 ? 0.0 : 2.0 * (x * y + y * z + z * x);
+    }
+};
+void split_sah(std::vector<int> &ids, size_t b, size_t e, size_t k, size_t cap, const HostScene &s, const std::vector<Centroid> &cen,
+               const std::vector<VBox> &tbox, std::vector<size_t> &sizes) {
+    const size_t n = e - b;
+    if (k <= 1) {
+        sizes.push_back(n);
+        return;
+    }
+    const size_t k1 = k / 2, k2 = k - k1;
+    // n_left must leave no more than k2 * cap on the right, no more than k1 * cap on the left, and at least k1 / k2
+    // triangles on each side (no empty child)
+    const size_t lo = std::max(k1, n > k2 * cap ? n - k2 * cap : 0), hi = std::min(n - k2, k1 * cap);
+    double best_cost = INFINITY;
+    int best_axis = 0;
+    size_t best_at = (lo + hi) / 2;
+    std::vector<int> sorted(ids.begin() + b, ids.begin() + e), best_order;
+    std::vector<double> right_area(n + 1);
+    for (int axis = 0; axis < 3; ++axis) {
+        const GeoLess less{&s, &cen, axis};
+        std::sort(sorted.begin(), sorted.end(), less);
+        VBox acc;
+        acc.reset();
+        right_area[n] = 0;
+        for (size_t i = n; i-- > 0;) {
+            acc.add(tbox[sorted[i]]);
+            right_area[i] = acc.area();
+        }
+        acc.reset();
+        for (size_t i = 1; i < n; ++i) {   // left = sorted[0, i)
+            acc.add(tbox[sorted[i - 1]]);
+            if (i < lo || i > hi) continue;
+            const double cost = acc.area() * static_cast<double>(i) + right_area[i] * static_cast<double>(n - i);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_axis = axis;
+                best_at = i;
+                (void)best_axis;
+            }
+        }
+        if (best_axis == axis && best_cost < INFINITY) best_order = sorted;
+    }
+    if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), ids.begin() + b);
+    split_sah(ids, b, b + best_at, k1, cap, s, cen, tbox, sizes);
+    split_sah(ids, b + best_at, e, k2, cap, s, cen, tbox, sizes);
+}
+
+// Orders ids[b, e) so that every aligned run of 8^L consecutive entries (L = 1, 2, ...) is spatially compact: the
+// implicit 8-ary sphere tree of a small-scene cluster is laid over this order.
+void arrange_implicit(std::vector<int> &ids, size_t b, size_t e, const HostScene &s, const std::vector<Centroid> &cen) {
+    const size_t n = e - b;
+    if (n <= static_cast<size_t>(kFan)) {   // a leaf group: canonical order, whatever order the triangles arrived in
+        std::sort(ids.begin() + b, ids.begin() + e, GeoLess{&s, &cen, 0});
+        return;
+    }
+    size_t cap = kFan;   // capacity of one child subtree
+    while (cap * kFan < n) cap *= kFan;
+    std::vector<size_t> sizes;
+    for (size_t left = n; left > 0; left -= std::min(left, cap)) sizes.push_back(std::min(left, cap));
+    partition_groups(ids, b, sizes, 0, sizes.size(), s, cen);
+    size_t at = b;
+    for (size_t sz : sizes) {
+        arrange_implicit(ids, at, at + sz, s, cen);
+        at += sz;
+    }
+}
+
+struct UnionFind {
+    std::vector<int> p;
+    explicit UnionFind(int n) : p(n) { for (int i = 0; i < n; ++i) p[i] = i; }
+    int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+    void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
+};
+
+struct Box {
+    double lo[3], hi[3];
+    void grow(const Box &b) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+    }
+};
+const Box kEmptyBox = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+
+// Axis-aligned box of every point Triangle::Intersect can accept for this triangle (DESIGN.md "Culling"): barycentric
+// coordinates >= -m_geo (the triangle grown about its centroid: vertex k moves to v_k + m (2 v_k - v_i - v_j)), at most
+// h_max off the triangle's own plane (displacement h_max |n_axis| per axis), plus the float rounding of
+// P* = o + d t* (eps_line).
+Box acceptance_box(const TriGeo &g, double eps_line) {
+    Box b = kEmptyBox;
+    const double m = g.m_geo * PT_MUT(box);
+    for (int k = 0; k < 3; ++k) {
+        const V3 &v = g.v[k], &a = g.v[(k + 1) % 3], &c = g.v[(k + 2) % 3];
+        const double p[3] = {v.x + m * (2 * v.x - a.x - c.x), v.y + m * (2 * v.y - a.y - c.y), v.z + m * (2 * v.z - a.z - c.z)};
+        for (int x = 0; x < 3; ++x) { b.lo[x] = std::min(b.lo[x], p[x]); b.hi[x] = std::max(b.hi[x], p[x]); }
+    }
+    const V3 nn = crs(sub(g.v[1], g.v[0]), sub(g.v[2], g.v[0]));
+    const double len = nrm(nn);
+    const double n[3] = {std::fabs(nn.x) / len, std::fabs(nn.y) / len, std::fabs(nn.z) / len};
+    for (int x = 0; x < 3; ++x) {
+        const double pad = (g.h_max * n[x] * (1.0 + 1e-9) + eps_line) * PT_MUT(box);
+        b.lo[x] -= pad;
+        b.hi[x] += pad;
+    }
+    return b;
+}
+
+// Box tree of a big scene over the (non-degenerate, small) triangles `ids`: uniform depth, up to 8 children per node,
+// every node's triangles split into spatially compact children of (nearly) equal size.  Appends the tree's slots
+// (8 per leaf, -1 = empty) to `order`, which must be empty: the tree's slots are the first slots.
+void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::vector<Centroid> &cen, std::vector<int> ids,
+               double eps_line, CullTables &out, std::vector<int> &order) {
+    out.bvh.clear();
+    out.bvh_leaf0 = 0;
+    out.bvh_err = static_cast<float>(4.0e-7 * PT_MUT(box_err));
+    const size_t n = ids.size();
+    if (n == 0) return;
+    std::vector<VBox> tbox(geo.size());
+    for (int t : ids) {
+        tbox[t].reset();
+        for (const V3 &v : geo[t].v) {
+            const double p[3] = {v.x, v.y, v.z};
+            for (int x = 0; x < 3; ++x) { tbox[t].lo[x] = std::min(tbox[t].lo[x], p[x]); tbox[t].hi[x] = std::max(tbox[t].hi[x], p[x]); }
+        }
+    }
+    int top = 1;
+    for (size_t cap = kFan; cap < n; cap *= kFan) ++top;
+    struct Range { size_t b, e; };
+    std::vector<std::vector<Range>> levels(top + 1);       // levels[L] = nodes of level L in BFS order; level 1 = leaves
+    std::vector<std::vector<uint32_t>> child_base(top + 1);
+    levels[top].push_back({0, n});
+    for (int L = top; L >= 2; --L) {
+        size_t cap = 1;
+        for (int k = 0; k < L - 1; ++k) cap *= kFan;       // capacity of a child
+        for (const Range &r : levels[L]) {
+            // as many children as keeps them about three quarters full (room for the cuts to follow the scene's objects),
+            // never fewer than the capacity demands
+            const size_t cnt = r.e - r.b, k_min = (cnt + cap - 1) / cap;
+            const size_t k = std::min<size_t>(std::min<size_t>(kFan, cnt), std::max(k_min, (4 * cnt + 3 * cap - 1) / (3 * cap)));
+            std::vector<size_t> sizes;
+            split_sah(ids, r.b, r.e, k, cap, s, cen, tbox, sizes);
+            child_base[L].push_back(static_cast<uint32_t>(levels[L - 1].size()));
+            size_t at = r.b;
+            for (size_t sz : sizes) {
+                levels[L - 1].push_back({at, at + sz});
+                at += sz;
+            }
+        }
+    }
+    // node indices: level `top` first, leaves last
+    std::vector<size_t> level_first(top + 2, 0);
+    size_t total = 0;
+    for (int L = top; L >= 1; --L) { level_first[L] = total; total += levels[L].size(); }
+    out.bvh_leaf0 = static_cast<uint32_t>(level_first[1]);
+    out.bvh.resize(total);
+    std::vector<Box> node_box(total, kEmptyBox);
+    std::vector<std::vector<Box>> kid_box(total);
+    // leaves: slots and triangle boxes
+    order.assign(levels[1].size() * kFan, -1);
+    for (size_t j = 0; j < levels[1].size(); ++j) {
+        const Range &r = levels[1][j];
+        const size_t node = level_first[1] + j;
+        std::sort(ids.begin() + r.b, ids.begin() + r.e, GeoLess{&s, &cen, 0});   // canonical order inside a leaf
+        for (size_t c = 0; c < r.e - r.b; ++c) {
+            order[j * kFan + c] = ids[r.b + c];
+            kid_box[node].push_back(acceptance_box(geo[ids[r.b + c]], eps_line));
+            node_box[node].grow(kid_box[node].back());
+        }
+    }
+    // internal nodes, bottom-up
+    for (int L = 2; L <= top; ++L)
+        for (size_t j = 0; j < levels[L].size(); ++j) {
+            const size_t node = level_first[L] + j;
+            const size_t first = level_first[L - 1] + child_base[L][j];
+            const size_t k = (j + 1 < levels[L].size() ? child_base[L][j + 1] : levels[L - 1].size()) - child_base[L][j];
+            for (size_t c = 0; c < k; ++c) {
+                kid_box[node].push_back(node_box[first + c]);
+                node_box[node].grow(node_box[first + c]);
+            }
+        }
+    // quantise: children as 8-bit boxes in the node's frame, rounded outward
+    for (size_t node = 0; node < total; ++node) {
+        BvhNode &q = out.bvh[node];
+        std::memset(&q, 0, sizeof q);
+        const Box &nb = node_box[node];
+        double extent = 0;
+        for (int x = 0; x < 3; ++x) {
+            float f = static_cast<float>(nb.lo[x]);
+            if (static_cast<double>(f) > nb.lo[x]) f = std::nextafterf(f, -INFINITY);
+            q.org[x] = f;
+            extent = std::max(extent, nb.hi[x] - static_cast<double>(f));
+        }
+        int e = extent > 0 ? static_cast<int>(std::ceil(std::log2(extent / 255.0))) : -100;
+        e = std::max(-100, std::min(100, e));
+        while (std::ceil(extent / std::ldexp(1.0, e)) > 255.0) ++e;
+        const double step = std::ldexp(1.0, e);
+        const size_t k = kid_box[node].size();
+        for (size_t c = 0; c < k; ++c)
+            for (int x = 0; x < 3; ++x) {
+                const double lo = std::floor((kid_box[node][c].lo[x] - static_cast<double>(q.org[x])) / step);
+                const double hi = std::ceil((kid_box[node][c].hi[x] - static_cast<double>(q.org[x])) / step);
+                q.lo[x][c] = static_cast<uint8_t>(std::max(0.0, std::min(255.0, lo)));
+                q.hi[x][c] = static_cast<uint8_t>(std::max(0.0, std::min(255.0, hi)));
+            }
+        uint32_t base = 0;
+        if (node < level_first[1]) {   // internal: index of the first child node
+            int L = top;
+            while (node >= level_first[L] + levels[L].size()) --L;
+            base = static_cast<uint32_t>(level_first[L - 1] + child_base[L][node - level_first[L]]);
+        }
+        q.meta = static_cast<uint32_t>(e + 127) | (static_cast<uint32_t>(k - 1) << 8) | (base << 11);
+    }
+}
+
+}  // namespace
+
 void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     const int T = s.n_tri();
     const double eps = eps_f;
@@ -298,23 +580,30 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     const double disc_err = 24.0 * kU * d_max * d_max;
 
     std::vector<TriGeo> geo(T);
-    for (int i = 0; i < T; ++i) geo[i] = tri_geometry(&s.tri[14 * static_cast<size_t>(i)], eps);
+    std::vector<Centroid> cen(T);
+    for (int i = 0; i < T; ++i) {
+        geo[i] = tri_geometry(&s.tri[14 * static_cast<size_t>(i)], eps);
+        const V3 *v = geo[i].v;
+        cen[i] = {{(v[0].x + v[1].x + v[2].x) / 3, (v[0].y + v[1].y + v[2].y) / 3, (v[0].z + v[1].z + v[2].z) / 3}};
+    }
 
-    auto sphere_of = [&](int first, int count, SphereRec &rec) {
+    // bounding sphere of the acceptance regions of the triangles ids[first, first + count)
+    auto sphere_of = [&](const int *ids, int count, SphereRec &rec) {
         std::vector<V3> pts;
         bool inf = false;
-        for (int i = first; i < first + count; ++i) {
-            if (geo[i].degenerate) inf = true;
-            for (const V3 &v : geo[i].v) pts.push_back(v);
+        for (int k = 0; k < count; ++k) {
+            if (geo[ids[k]].degenerate) inf = true;
+            for (const V3 &v : geo[ids[k]].v) pts.push_back(v);
         }
         V3 c; double rad;
         bounding_sphere(pts, c, rad);
         double reff = 0;
-        for (int i = first; i < first + count && !inf; ++i) {
+        for (int k = 0; k < count && !inf; ++k) {
+            const TriGeo &g = geo[ids[k]];
             double dmax = 0;
-            for (const V3 &v : geo[i].v) dmax = std::max(dmax, nrm(sub(v, c)));
+            for (const V3 &v : g.v) dmax = std::max(dmax, nrm(sub(v, c)));
             // accepted point = sum(lambda_k v_k) + h n, lambda_k >= -m_geo  =>  |P - c| <= (1 + 4 m_geo) dmax + h_max
-            reff = std::max(reff, (1.0 + 4.0 * geo[i].m_geo) * dmax + geo[i].h_max + eps_line);
+            reff = std::max(reff, (1.0 + 4.0 * g.m_geo) * dmax + g.h_max + eps_line);
         }
         rec.c[0] = static_cast<float>(c.x); rec.c[1] = static_cast<float>(c.y); rec.c[2] = static_cast<float>(c.z);
         // the centre is rounded to float: grow by that displacement
@@ -325,77 +614,208 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         return inf ? INFINITY : reff;
     };
 
-    // ---- classes: a triangle whose own sphere is a sizeable part of the scene is culled by the barycentric test
+    // ---- classes.  LARGE: a triangle whose own sphere is a sizeable part of the scene (walls) -- and every triangle
+    // that cannot be bounded at all (degenerate) -- is culled by a barycentric record, wave-uniformly.  SMALL: the rest,
+    // under a hierarchy of bounding volumes.
     std::vector<uint8_t> large(T);
-    double a_max = 0, inv_2s_max = 0, diam2_2s_max = 0, quad_slack = 0;
     for (int i = 0; i < T; ++i) {
         SphereRec tmp;
-        const double reff = sphere_of(i, 1, tmp);
+        const double reff = sphere_of(&i, 1, tmp);
         large[i] = !(reff < 0.12 * r_max);
     }
-    // A run of one or two small triangles between two large runs (the light of a room, listed between its walls) costs
-    // more as a cluster of its own -- descriptor, sphere tests, a publication -- than as one more record of the large run.
+    // connected groups of small triangles (triangles sharing a vertex position): the objects of the scene
+    UnionFind uf(T);
+    {
+        struct Key { uint32_t b[3]; int tri; };
+        std::vector<Key> keys;
+        for (int i = 0; i < T; ++i)
+            if (!large[i])
+                for (int v = 0; v < 3; ++v) {
+                    Key k;
+                    std::memcpy(k.b, &s.tri[14 * static_cast<size_t>(i) + 4 + 3 * v], 12);
+                    k.tri = i;
+                    keys.push_back(k);
+                }
+        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+            const int m = std::memcmp(a.b, b.b, 12);
+            return m != 0 ? m < 0 : a.tri < b.tri;
+        });
+        for (size_t k = 1; k < keys.size(); ++k)
+            if (std::memcmp(keys[k].b, keys[k - 1].b, 12) == 0) uf.unite(keys[k].tri, keys[k - 1].tri);
+    }
+    std::vector<std::vector<int>> groups;   // small triangles by connected group
+    {
+        std::vector<int> group_of(T, -1);
+        for (int i = 0; i < T; ++i) {
+            if (large[i]) continue;
+            const int r = uf.find(i);
+            if (group_of[r] < 0) { group_of[r] = static_cast<int>(groups.size()); groups.emplace_back(); }
+            groups[group_of[r]].push_back(i);
+        }
+    }
+    // A group of one or two small triangles (the light of a room) costs more as a cluster of its own -- descriptor, sphere
+    // tests, a publication per segment -- than as one more record of the large class ...
 #ifdef PT_TEST_HOOKS
     const bool absorb = !g_cull_mutation.no_absorb;
 #else
     const bool absorb = true;
 #endif
-    if (absorb) {
-        for (int b = 0; b < T;) {
-            int e = b;
-            while (e < T && large[e] == large[b]) ++e;
+    bool any_large = false;
+    for (int i = 0; i < T; ++i) any_large |= large[i] != 0;
+    if (absorb && any_large && T <= kBigSceneTriangles) {
+        for (auto &g : groups) {
             // ... unless they are so small that their barycentric gradients (1 / height) would blow up the margin of
             // the whole class: the test of every large triangle uses the class-wide a_max
-            bool fits = !large[b] && e - b <= 2 && b > 0 && e < T;
-            for (int k = b; k < e && fits; ++k) fits = !geo[k].degenerate && geo[k].a_max * r_max <= 64.0;
-            if (fits)
-                for (int k = b; k < e; ++k) large[k] = 1;
-            b = e;
+            bool fits = g.size() <= 2;
+            for (int t : g) fits = fits && !geo[t].degenerate && geo[t].a_max * r_max <= 64.0;
+            if (!fits) continue;
+            for (int t : g) large[t] = 1;
+            g.clear();
+        }
+        groups.erase(std::remove_if(groups.begin(), groups.end(), [](const std::vector<int> &g) { return g.empty(); }), groups.end());
+    }
+    const bool big = T > kBigSceneTriangles;
+
+    // ---- slot order of the small class
+    std::vector<int> order;                       // slot -> triangle (-1 = padding)
+    std::vector<std::pair<int, int>> small_runs;  // small scenes: [first slot, count) of each cluster
+    if (big) {
+        std::vector<int> ids;
+        for (const auto &g : groups) ids.insert(ids.end(), g.begin(), g.end());
+        build_bvh(s, geo, cen, ids, eps_line, out, order);
+    } else if (!groups.empty()) {
+        if (static_cast<int>(groups.size()) > kMaxClusters) {   // a cloud of loose triangles: one tree over all of them
+            std::vector<int> all;
+            for (const auto &g : groups) all.insert(all.end(), g.begin(), g.end());
+            groups.assign(1, all);
+        }
+        // clusters in an order that depends on geometry only
+        std::vector<std::pair<Centroid, size_t>> keyed;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            Centroid m = {{0, 0, 0}};
+            for (int t : groups[g]) for (int k = 0; k < 3; ++k) m.c[k] += cen[t].c[k] / static_cast<double>(groups[g].size());
+            keyed.push_back({m, g});
+        }
+        std::sort(keyed.begin(), keyed.end(), [](const std::pair<Centroid, size_t> &a, const std::pair<Centroid, size_t> &b) {
+            for (int k = 0; k < 3; ++k) if (a.first.c[k] != b.first.c[k]) return a.first.c[k] < b.first.c[k];
+            return a.second < b.second;
+        });
+        for (const auto &kg : keyed) {
+            std::vector<int> ids = groups[kg.second];
+            arrange_implicit(ids, 0, ids.size(), s, cen);
+            small_runs.push_back({static_cast<int>(order.size()), static_cast<int>(ids.size())});
+            order.insert(order.end(), ids.begin(), ids.end());
         }
     }
-    // ---- clusters: maximal runs of consecutive triangles of one class
+    const int n_small_slots = static_cast<int>(order.size());
+
+    // ---- slot order of the large class: coplanar pairs that share an edge first (they become quad records), then singles
+    {
+        std::vector<int> lg;
+        for (int i = 0; i < T; ++i) if (large[i]) lg.push_back(i);
+        const GeoLess less{&s, &cen, 0};
+        std::sort(lg.begin(), lg.end(), less);
+        std::vector<uint8_t> used(lg.size(), 0);
+        std::vector<int> pairs, singles;
+        for (size_t a = 0; a < lg.size(); ++a) {
+            if (used[a]) continue;
+            const float *ra = &s.tri[14 * static_cast<size_t>(lg[a])];
+            int mate = -1;
+            for (size_t b = a + 1; b < lg.size() && mate < 0 && !geo[lg[a]].degenerate; ++b) {
+                if (used[b] || geo[lg[b]].degenerate) continue;
+                const float *rb = &s.tri[14 * static_cast<size_t>(lg[b])];
+                if (std::memcmp(ra, rb, 16) != 0) continue;   // ONE stored plane
+                int shared = 0;
+                for (int x = 0; x < 3; ++x)
+                    for (int y = 0; y < 3; ++y) shared += std::memcmp(ra + 4 + 3 * x, rb + 4 + 3 * y, 12) == 0;
+                if (shared == 2) mate = static_cast<int>(b);
+            }
+            if (mate >= 0) {
+                used[a] = used[mate] = 1;
+                pairs.push_back(lg[a]);
+                pairs.push_back(lg[mate]);
+            } else {
+                used[a] = 1;
+                singles.push_back(lg[a]);
+            }
+        }
+        order.insert(order.end(), pairs.begin(), pairs.end());
+        order.insert(order.end(), singles.begin(), singles.end());
+    }
+    const int n_slots = static_cast<int>(order.size());
+    const int n_large = n_slots - n_small_slots;
+
+    // ---- tables in slot order
+    out.slot_tri.resize(n_slots);
+    out.exact_slot.resize(n_slots);
+    DeviceTables dev_tables;
+    build_device_tables(s, dev_tables);
+    for (int k = 0; k < n_slots; ++k) {
+        out.slot_tri[k] = order[k] < 0 ? kNoTriangle : static_cast<uint32_t>(order[k]);
+        if (order[k] >= 0) {
+            out.exact_slot[k] = dev_tables.exact[order[k]];
+        } else {
+            ExactRec e;
+            std::memset(&e, 0, sizeof e);
+            e.plane[0] = e.plane[1] = e.plane[2] = e.plane[3] = NAN;   // a padding slot can never be accepted
+            e.orig = -1;
+            out.exact_slot[k] = e;
+        }
+    }
+
+    double a_max = 0, inv_2s_max = 0, diam2_2s_max = 0, quad_slack = 0;
     const SphereRec never = {{0, 0, 0}, -1.0e30f};
-    int i = 0;
-    while (i < T) {
-        const bool lg = large[i];
-        int n = 1;
-        while (i + n < T && large[i + n] == lg) ++n;
+    // ---- small-scene clusters: an implicit 8-ary tree of bounding spheres over each run of slots
+    for (const auto &run : small_runs) {
+        const int i = run.first, n = run.second;
         ClusterDesc cd;
         std::memset(&cd, 0, sizeof cd);
         SphereRec cs;
-        sphere_of(i, n, cs);
+        sphere_of(&order[i], n, cs);
         cd.c[0] = cs.c[0]; cd.c[1] = cs.c[1]; cd.c[2] = cs.c[2]; cd.r2 = cs.r2;
         cd.first_tri = static_cast<uint32_t>(i);
         cd.n_tri = static_cast<uint32_t>(n);
-        cd.kind = lg ? 1u : 0u;
-        const int n_words = (n + kChunk - 1) / kChunk;
-        if (!lg) {
-            cd.data_off = static_cast<uint32_t>(out.spheres.size());
-            long long span = 1;   // triangles per node of the current level
-            for (int level = 0;; ++level, span *= kFan) {
-                const long long count = (n + span - 1) / span;
-                if (level > 0) cd.level_off[level - 1] = static_cast<uint32_t>(out.spheres.size() - cd.data_off);
-                for (long long j = 0; j < (count + kFan - 1) / kFan * kFan; ++j) {
-                    SphereRec sr = never;
-                    if (j < count) {
-                        const long long f = j * span;
-                        sphere_of(i + static_cast<int>(f), static_cast<int>(std::min<long long>(span, n - f)), sr);
-                    }
-                    out.spheres.push_back(sr);
+        cd.kind = 0u;
+        cd.data_off = static_cast<uint32_t>(out.spheres.size());
+        long long span = 1;   // triangles per node of the current level
+        for (int level = 0;; ++level, span *= kFan) {
+            const long long count = (n + span - 1) / span;
+            if (level > 0) cd.level_off[level - 1] = static_cast<uint32_t>(out.spheres.size() - cd.data_off);
+            for (long long j = 0; j < (count + kFan - 1) / kFan * kFan; ++j) {
+                SphereRec sr = never;
+                if (j < count) {
+                    const long long f = j * span;
+                    sphere_of(&order[i + static_cast<int>(f)], static_cast<int>(std::min<long long>(span, n - f)), sr);
                 }
-                if (count <= kFan || level == kMaxLevels - 1) {
-                    cd.n_levels = static_cast<uint32_t>(level + 1);
-                    break;
-                }
+                out.spheres.push_back(sr);
             }
-        } else {
+            if (count <= kFan || level == kMaxLevels - 1) {
+                cd.n_levels = static_cast<uint32_t>(level + 1);
+                break;
+            }
+        }
+        out.clusters.push_back(cd);
+    }
+    // ---- the large class: one cluster of barycentric records
+    if (n_large > 0) {
+        const int i = n_small_slots, n = n_large;
+        ClusterDesc cd;
+        std::memset(&cd, 0, sizeof cd);
+        SphereRec cs;
+        sphere_of(&order[i], n, cs);
+        cd.c[0] = cs.c[0]; cd.c[1] = cs.c[1]; cd.c[2] = cs.c[2]; cd.r2 = cs.r2;
+        cd.first_tri = static_cast<uint32_t>(i);
+        cd.n_tri = static_cast<uint32_t>(n);
+        cd.kind = 1u;
+        const int n_words = (n + kChunk - 1) / kChunk;
+        {
             cd.data_off = static_cast<uint32_t>(out.bary.size());
             for (int k = 0; k < n_words * kChunk; ++k) {
                 CullRec c;
                 std::memset(&c, 0, sizeof c);
                 if (k < n) {
-                    const float *r = &s.tri[14 * static_cast<size_t>(i + k)];
-                    const TriGeo &g = geo[i + k];
+                    const float *r = &s.tri[14 * static_cast<size_t>(order[i + k])];
+                    const TriGeo &g = geo[order[i + k]];
                     const V3 e1 = sub(g.v[1], g.v[0]), e2 = sub(g.v[2], g.v[0]);
                     const V3 nn = crs(e1, e2);
                     const double s2 = dt(nn, nn);
@@ -428,8 +848,8 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
             for (int w = 0; w < n_words && w < kMaxLevels - 1; ++w) {
                 uint32_t qmask = 0;
                 for (int k = w * kChunk; k + 1 < std::min(n, (w + 1) * kChunk); k += 2) {
-                    const float *ra = &s.tri[14 * static_cast<size_t>(i + k)], *rb = &s.tri[14 * static_cast<size_t>(i + k + 1)];
-                    if (std::memcmp(ra, rb, 16) != 0 || geo[i + k].degenerate || geo[i + k + 1].degenerate) continue;
+                    const float *ra = &s.tri[14 * static_cast<size_t>(order[i + k])], *rb = &s.tri[14 * static_cast<size_t>(order[i + k + 1])];
+                    if (std::memcmp(ra, rb, 16) != 0 || geo[order[i + k]].degenerate || geo[order[i + k + 1]].degenerate) continue;
                     // shared vertices (bitwise) and the two apexes
                     int sa[2], sb[2], ns = 0, apex_a = -1, apex_b = -1;
                     bool used_b[3] = {false, false, false};
@@ -442,8 +862,8 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
                     }
                     if (ns != 2 || apex_a < 0) continue;
                     for (int y = 0; y < 3; ++y) if (!used_b[y]) apex_b = y;
-                    const TriGeo &ga = geo[i + k], &gb = geo[i + k + 1];
-                    const V3 s0 = ga.v[sa[0]], s1 = ga.v[sa[1]], pa = ga.v[apex_a], pb = gb.v[apex_b];
+                    const TriGeo &ga = geo[order[i + k]], &gb = geo[order[i + k + 1]];
+                    const V3 s0 = ga.v[sa[0]], pa = ga.v[apex_a], pb = gb.v[apex_b];
                     const V3 ea = sub(pa, s0), eb = sub(pb, s0);
                     const V3 nn = crs(ea, eb);
                     const double s2 = dt(nn, nn);
@@ -493,7 +913,6 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
             }
         }
         out.clusters.push_back(cd);
-        i += n;
     }
     // keep the tables non-empty and padded so that speculative wide scalar loads stay inside the allocation
     for (int k = 0; k < 16; ++k) out.spheres.push_back(never);
@@ -501,13 +920,14 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
 
     // ---- big scenes: a barycentric record for every triangle, used to thin the (ray, triangle) pairs before the exact test
     double a_max_all = 0, inv_2s_max_all = 0, diam2_2s_max_all = 0;
-    if (T > kBigSceneTriangles) {
-        out.bary_all.resize(static_cast<size_t>(T) + 4);
+    if (big) {
+        out.bary_all.resize(static_cast<size_t>(n_slots) + 4);
         for (auto &c : out.bary_all) std::memset(&c, 0, sizeof c);
-        for (int k = 0; k < T; ++k) {
+        for (int k = 0; k < n_slots; ++k) {
+            if (order[k] < 0) continue;   // padding slots are never candidates
             CullRec &c = out.bary_all[k];
-            const float *r = &s.tri[14 * static_cast<size_t>(k)];
-            const TriGeo &g = geo[k];
+            const float *r = &s.tri[14 * static_cast<size_t>(order[k])];
+            const TriGeo &g = geo[order[k]];
             const V3 e1 = sub(g.v[1], g.v[0]), e2 = sub(g.v[2], g.v[0]);
             const V3 nn = crs(e1, e2);
             const double s2 = dt(nn, nn);

@@ -34,13 +34,16 @@ struct CullRec {
     float au[3], cu;
     float av[3], cv;
 };
-// Exact record: 16 floats, gathered per lane only for the few triangles that survive culling.
+// Exact record: 16 floats, gathered per lane only for the few triangles that survive culling.  Two tables hold them:
+// one in the ORIGINAL triangle order (shading, the reference's all-triangles loop) and one in SLOT order (below), where
+// `orig` carries the original index for the (distance, index) tie-break of scene.cpp:116-120.
 struct ExactRec {
     float plane[4];
     float v0[3], square;
     float v1[3];
     int32_t material;
-    float v2[3], pad;
+    float v2[3];
+    int32_t orig;
 };
 // Material record (Factory's lobe table, material.h:58-106).
 struct MatRec {
@@ -57,7 +60,25 @@ static const int kMaxLevels = 8; // small class: tree levels per cluster (8^8 tr
 #define PT_TILE_W 8
 #endif
 static const int kTileW = PT_TILE_W, kTileH = 64 / PT_TILE_W;
-static const int kBigSceneTriangles = 2048;   // above this the kernel uses deep queues and pre-filters (ray, triangle) pairs
+static const int kBigSceneTriangles = 2048;   // above this the kernel walks one box tree over all small triangles, with deep queues
+static const int kMaxClusters = 8;            // small scenes: more connected groups than this are merged into one cluster
+
+// SLOT ORDER.  The culling hierarchy does not follow the file order of the triangles: the table builder groups them
+// spatially and lays them out in its own order; "slot" = position in that order (pairs, candidate masks and cluster
+// ranges are all in slots).  Slots without a triangle (padding of the box tree's leaves) map to kNoTriangle.
+static const uint32_t kNoTriangle = 0xFFFFFFFFu;
+
+// Box tree of big scenes: one node = a frame (lower corner + one power-of-two step) and up to 8 children as 8-bit boxes in
+// that frame.  64 bytes = four 16-byte loads per (ray, node) item.  All leaves are on one level: nodes [0, leaf0) are
+// internal (children = nodes child_base + c), nodes [leaf0, n) are leaves (children = slots 8 * (node - leaf0) + c).
+// Child boxes are rounded OUTWARD, so a dequantised box always contains the true one.
+struct BvhNode {
+    float org[3];
+    uint32_t meta;       // biased exponent of the step (bits 0-7) | children - 1 (bits 8-10) | child_base (bits 11-31)
+    uint8_t lo[3][8];    // per axis, per child: lower bound in steps from org
+    uint8_t hi[3][8];    // upper bound
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode is four 16-byte loads");
 
 // Bounding sphere used by the hierarchical cull: a ray is kept for the node iff its distance to `c` is <= sqrt(r2).
 // r2 already contains every slack that makes the test conservative (see DESIGN.md "Culling").
@@ -90,11 +111,16 @@ struct CullConstants {
 
 // Everything the cull stage reads; depends on eps, so a scene caches one set per eps value.
 struct CullTables {
+    std::vector<uint32_t> slot_tri;  // slot -> original triangle index (kNoTriangle for padding slots)
+    std::vector<ExactRec> exact_slot;// exact records in slot order
     std::vector<SphereRec> spheres;
     std::vector<CullRec> bary;
-    std::vector<CullRec> bary_all;   // big scenes only: a barycentric record for EVERY triangle (pair pre-filter)
+    std::vector<CullRec> bary_all;   // big scenes only: a barycentric record for EVERY slot (pair pre-filter)
     CullConstants cc_all;            // its margins (they must cover the smallest triangle of the scene)
     std::vector<ClusterDesc> clusters;
+    std::vector<BvhNode> bvh;        // big scenes only: box tree over the small triangles (slots [0, 8 * leaves))
+    uint32_t bvh_leaf0 = 0;          // index of the first leaf node
+    float bvh_err = 0;               // relative rounding allowance of the kernel's slab arithmetic
     CullConstants cc;
     float eps = 0;
     float r_org = 0;                 // the margins hold for ray origins with every |component| <= r_org
@@ -104,7 +130,7 @@ struct CullTables {
 // Test build only (libpt_testhooks.so): scale factors on each family of conservative margins, so that the test suite can
 // show it notices a cull that is too tight (tests/test_gpu_mutation.py).  The shipped library has no such knob.
 struct CullMutation {
-    double sphere_r2 = 1, m0 = 1, k12 = 1, a_max = 1, quad_slack = 1;
+    double sphere_r2 = 1, m0 = 1, k12 = 1, a_max = 1, quad_slack = 1, box = 1, box_err = 1;
     int no_absorb = 0;
 };
 extern CullMutation g_cull_mutation;

@@ -25,7 +25,7 @@ int main(int argc, char **argv) {
         }
         pt::CullTables ct; pt::build_cull_tables(h, 1e-4f, ct);
         pt::DeviceTables d2; pt::build_device_tables(h, d2);
-        std::printf("n %d: %zu clusters %zu spheres %zu bary %zu bary_all\n", n, ct.clusters.size(), ct.spheres.size(), ct.bary.size(), ct.bary_all.size());
+        std::printf("n %d: %zu clusters %zu spheres %zu bary %zu bary_all %zu slots %zu bvh\n", n, ct.clusters.size(), ct.spheres.size(), ct.bary.size(), ct.bary_all.size(), ct.slot_tri.size(), ct.bvh.size());
     }
     // malformed OBJ files
     const char *bad[] = {"f 1 2 3\n", "mtllib nope.mtl\nv 0 0 0\n", "v 0 0\nf 1//1 2 3\n", "usemtl x\nv 1 2 3\nv 1 2 4\nv 2 2 2\nf 1 2 9\n", ""};

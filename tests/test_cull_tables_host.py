@@ -1,5 +1,8 @@
 """CPU checks of the culling hierarchy the host builds (pt_scene.cpp: build_cull_tables): structure, containment, and
-the property everything rests on -- a triangle the reference ACCEPTS for a ray is never culled for that ray."""
+the property everything rests on -- a triangle the reference ACCEPTS for a ray is never culled for that ray.
+
+The hierarchy lists the triangles in its own SLOT order (spatial grouping, independent of the file order); cluster
+ranges, sphere-tree leaves and box-tree leaves are slots, `cull_layout()["slot_triangle"]` maps them back."""
 import importlib
 import os
 import sys
@@ -21,7 +24,7 @@ def _ray_sphere_keep(c, r2, o, d):
 
 
 def _layout(t):
-    """triangle index -> (cluster, [sphere index of its ancestor at every level, top first ... level 0 last])."""
+    """slot -> (cluster, [sphere index of its ancestor at every level, top first ... level 0 last])."""
     out = {}
     for ci in range(len(t["kind"])):
         if t["kind"][ci] != 0:
@@ -47,7 +50,10 @@ def test_structure_tor(tor):
     assert list(t["level_off"][0][:3]) == [0, 256, 288]
     assert t["n_large"] == 14
     tri, _ = tor.triangles()
-    v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
+    st = tor.cull_layout()["slot_triangle"]
+    assert sorted(st) == list(range(270))                  # a permutation of the triangles, no padding in a small scene
+    assert sorted(st[:256]) == list(range(256))            # the torus (file triangles 0-255) is the sphere-tree cluster
+    v = tri[st, 4:13].reshape(-1, 3, 3).astype(np.float64)   # vertices by SLOT
     lay = _layout(t)
     assert sorted(lay) == list(range(256))
     for i, (ci, chain) in lay.items():
@@ -67,10 +73,12 @@ def test_accepted_triangles_are_never_culled(tor, oracle_scene):
     t = tor.cull_tables()
     lay = _layout(t)
     tri, _ = tor.triangles()
+    st = tor.cull_layout()["slot_triangle"]
+    slot_of = np.argsort(st)
     rng = np.random.default_rng(17)
     v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
     # rays aimed at random points of small triangles (inside, on edges, just outside), from random origins
-    small = np.array(sorted(lay))
+    small = np.array(sorted(st[k] for k in lay))
     n = 40000
     a = small[rng.integers(0, len(small), n)]
     w = rng.dirichlet([0.6, 0.6, 0.6], n) * rng.choice([1.0, 1.0, 1.001, 1.01], n)[:, None]
@@ -89,7 +97,7 @@ def test_accepted_triangles_are_never_culled(tor, oracle_scene):
         if stage != 4:
             continue
         accepted += 1
-        ci, chain = lay[int(a[i])]
+        ci, chain = lay[int(slot_of[a[i]])]
         o64, d64 = o32[i].astype(np.float64), d[i].astype(np.float64)
         for sph in [t["cluster_sphere"][ci]] + [t["spheres"][k] for k in chain]:
             assert _ray_sphere_keep(sph[:3].astype(np.float64), float(sph[3]), o64, d64)
@@ -98,30 +106,32 @@ def test_accepted_triangles_are_never_culled(tor, oracle_scene):
 
 def test_degenerate_and_tiny_triangles_are_always_kept(tmp_path):
     (tmp_path / "d.mtl").write_text("newmtl 0\nKd 1 1 1\n")
-    (tmp_path / "d.obj").write_text("mtllib d.mtl\nv 0 0 0\nv 1 0 0\nv 2 0 0\nv 0 0.001 0\nv 0.001 0 0\nv 5 5 5\nv 6 5 5\nv 5 6 5\n"
+    (tmp_path / "d.obj").write_text("mtllib d.mtl\nv 0 0 0\nv 1 0 0\nv 2 0 0\nv 0 0.001 0\nv 0.001 0 0\nv 5 5 5\nv 5.1 5 5\nv 5 5.1 5\n"
                                     "usemtl 0\nf 1 2 3\nf 1 4 5\nf 6 7 8\n")
     s = pt.Scene.load_obj(str(tmp_path) + "/", "d.obj", device=-1)
     t = s.cull_tables()
     lay = _layout(t)
     # collinear triangle 0 and the 1e-6-area triangle 1 (area below a few eps) cannot be bounded: they land in the
     # barycentric class with NaN coefficients, which makes every cull comparison false (always kept)
-    assert list(t["kind"]) == [1, 0] and list(t["n_tri"]) == [2, 1]
+    assert list(t["kind"]) == [0, 1] and list(t["n_tri"]) == [1, 2]      # the sphere-tree cluster first, the large class last
+    st = s.cull_layout()["slot_triangle"]
+    assert st[0] == 2 and sorted(st[1:]) == [0, 1]
     assert np.isnan(t["bary"][0, 4:]).all() and np.isnan(t["bary"][1, 4:]).all()
-    assert np.isfinite(t["bary"][0, :4]).any() or True   # the plane itself is whatever the reference computed
-    assert np.isinf(t["cluster_sphere"][0][3])
-    assert sorted(lay) == [2] and np.isfinite(t["spheres"][lay[2][1][-1]][3])
+    assert np.isinf(t["cluster_sphere"][1][3])
+    assert sorted(lay) == [0] and np.isfinite(t["spheres"][lay[0][1][-1]][3])
 
 
 def test_light_as_its_own_cluster_without_absorption(models_dir):
-    """The test build's `no_absorb` hook (a tuning knob of the table builder) restores the four runs of the file order."""
+    """The test build's `no_absorb` hook (a tuning knob of the table builder) keeps the light (a connected group of two
+    small triangles) as a sphere cluster of its own instead of two more records of the large class."""
     H = pt.load_library(pt.TESTHOOKS_LIB_PATH)
     H.pt_test_set_mutation(b"no_absorb", 1.0)
     try:
         t = pt.Scene.load_obj(models_dir, "Tor.obj", device=-1, library=H).cull_tables()
     finally:
         H.pt_test_set_mutation(b"reset", 0.0)
-    assert list(t["first_tri"]) == [0, 256, 258, 260] and list(t["n_tri"]) == [256, 2, 2, 10]
-    assert list(t["kind"]) == [0, 1, 0, 1] and list(t["n_levels"][[0, 2]]) == [3, 1] and t["n_large"] == 12
+    assert list(t["kind"]) == [0, 0, 1] and sorted(t["n_tri"][:2]) == [2, 256] and t["n_tri"][2] == 12
+    assert sorted(t["n_levels"][:2]) == [1, 3] and t["n_large"] == 12
 
 
 def test_tiny_run_between_walls_keeps_its_own_cluster(tmp_path):
@@ -135,7 +145,7 @@ def test_tiny_run_between_walls_keeps_its_own_cluster(tmp_path):
     lines += quad(5) + ["f 15 16 17", "f 15 17 18"]
     (tmp_path / "w.obj").write_text("\n".join(lines) + "\n")
     t = pt.Scene.load_obj(str(tmp_path) + "/", "w.obj", device=-1).cull_tables()
-    assert list(t["kind"]) == [1, 0, 1] and list(t["n_tri"]) == [2, 1, 5]
+    assert list(t["kind"]) == [0, 1] and list(t["n_tri"]) == [1, 7]     # the 5-cm triangle keeps its cluster, the 3-unit one is absorbed
 
 
 def test_tables_depend_on_eps(tor):
@@ -153,6 +163,7 @@ def test_quads_of_the_room_are_fused_and_never_cull_an_accepted_hit(tor, oracle_
     assert [int(t["level_off"][c][1]) for c in large] == [0b1010101010101]     # quad mask of word 0: walls and light, every pair fused
     k1, k2, a_max, m0 = (t["constants"][k] for k in ("k1", "k2", "a_max", "m0"))
     tri, _ = tor.triangles()
+    slot_tri = tor.cull_layout()["slot_triangle"]
     v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
     rng = np.random.default_rng(23)
     L = O.lib()
@@ -164,7 +175,7 @@ def test_quads_of_the_room_are_fused_and_never_cull_an_accepted_hit(tor, oracle_
             assert (mask >> k) & 1
             rec = t["bary"][off + k].astype(np.float64)
             for half in (0, 1):
-                ti = first + k + half
+                ti = int(slot_tri[first + k + half])      # slot -> original triangle
                 w = rng.dirichlet([0.5, 0.5, 0.5], 3000) * rng.choice([1.0, 1.0, 1.0005], 3000)[:, None]   # incl. edges / just outside
                 target = (v[ti] * w[:, :, None]).sum(1)
                 org = rng.uniform([-9.5, -9.5, -20.5], [9.5, 9.5, 9.5], (3000, 3))
@@ -187,3 +198,85 @@ def test_quads_of_the_room_are_fused_and_never_cull_an_accepted_hit(tor, oracle_
                     et = (k1 * abs(tt) + k2) / abs(den)
                     assert e >= -(a_max * et + m0) and tt >= -et, (ti, e, tt)
     assert checked > 10000
+
+
+def _shuffled_copy(models_dir, tmp, seed):
+    """Tor.obj with its faces in random order (each face keeps its material: usemtl is re-emitted per face)."""
+    lines = open(models_dir + "Tor.obj").read().split("\n")
+    head, faces, mtl = [], [], None
+    for l in lines:
+        if l.startswith("usemtl"):
+            mtl = l
+        elif l.startswith("f "):
+            faces.append((mtl, l))
+        else:
+            head.append(l)
+    perm = np.random.default_rng(seed).permutation(len(faces))
+    out = head + [x for k in perm for x in faces[k]]
+    open(tmp + "shuffled.obj", "w").write("\n".join(out) + "\n")
+    open(tmp + "Tor.mtl", "w").write(open(models_dir + "Tor.mtl").read())
+    return perm
+
+
+def test_hierarchy_does_not_depend_on_the_file_order(tmp_path, models_dir, tor):
+    d = str(tmp_path) + "/"
+    perm = _shuffled_copy(models_dir, d, 4)
+    sh = pt.Scene.load_obj(d, "shuffled.obj", device=-1)
+    a, b = tor.cull_tables(), sh.cull_tables()
+    for k in ("kind", "first_tri", "n_tri", "n_levels"):
+        assert list(a[k]) == list(b[k])
+    assert np.array_equal(a["spheres"].view(np.uint32), b["spheres"].view(np.uint32))       # the same tree, bit for bit
+    assert np.array_equal(a["bary"].view(np.uint32), b["bary"].view(np.uint32))
+    sa, sb = tor.cull_layout()["slot_triangle"], sh.cull_layout()["slot_triangle"]
+    ta, tb = tor.triangles()[0], sh.triangles()[0]
+    assert np.array_equal(ta[sa].view(np.uint32), tb[sb].view(np.uint32))                  # slot k holds the same geometry
+    assert np.array_equal(perm[sb], sa)                                                       # ... i.e. the same triangle
+
+
+def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path):
+    """Big scenes: the chain of box-tree nodes above the triangle the reference hits survives the kernel's slab test
+    (numpy restatement in float32, tests/bvh_emulation.py) for the tightest t_best the walk can hold: the hit's own t."""
+    import bvh_emulation as B
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_replicated_scene as M
+    d = str(tmp_path) + "/"
+    n_tri = M.generate(os.path.join(ROOT, "models"), d, "x9.obj", 9)
+    assert n_tri > 2048
+    g = pt.Scene.load_obj(d, "x9.obj", device=-1)
+    o = O.Scene.load(d, "x9.obj")
+    lay = g.cull_layout()
+    t, fl = B.decode(lay["bvh"]), lay["bvh_first_leaf"]
+    st = lay["slot_triangle"]
+    assert len(lay["bvh"]) > fl > 0 and sorted(st[st >= 0]) == list(range(n_tri))
+    n_tree_slots = (len(lay["bvh"]) - fl) * 8
+    assert (st[n_tree_slots:] >= 0).all()                          # padding only inside the tree's leaves
+    par, pos = B.parents(t, fl)
+    assert (par[1:] >= 0).all() and par[0] == -1                   # one root, every other node has a parent
+    slot_of = np.full(n_tri, -1)
+    slot_of[st[st >= 0]] = np.flatnonzero(st >= 0)
+    tri, _ = o.triangles()
+    rng = np.random.default_rng(8)
+    n = 60000
+    v = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
+    a = rng.integers(0, n_tri, n)
+    w = rng.dirichlet([1, 1, 1], n)
+    src = ((v[a] * w[:, :, None]).sum(1) + tri[a, 0:3] * 1e-4).astype(np.float32)
+    dd = rng.normal(size=(n, 3)).astype(np.float32)
+    dd[::7, 0] = 0                                                  # some axis-parallel components (the 1e-30 substitution)
+    inv = np.float32(1) / np.sqrt((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2], dtype=np.float32)
+    dd = (dd * inv[:, None]).astype(np.float32)
+    hi, ht, nan = o.closest_hits(src, dd)
+    ok = (hi >= 0) & ~nan
+    ok &= slot_of[np.maximum(hi, 0)] < n_tree_slots                 # hits on triangles of the tree (not the walls)
+    ro, rd, tb, sl = src[ok], dd[ok], ht[ok], slot_of[hi[ok]]
+    assert len(sl) > 10000
+    node, child = fl + sl // 8, sl % 8
+    levels = 0
+    while len(node):
+        kept = B.children_kept(t, node, ro, rd, tb, 4e-7)
+        assert kept[np.arange(len(node)), child].all(), f"a node of level {levels} above a hit was dropped"
+        child, node = pos[node], par[node]
+        live = node >= 0
+        node, child, ro, rd, tb = node[live], child[live], ro[live], rd[live], tb[live]
+        levels += 1
+    assert levels >= 3

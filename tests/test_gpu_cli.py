@@ -47,4 +47,18 @@ def test_cli_out_flag_and_time_limit(tmp_path, models_dir):
     assert r.returncode == 0, r.stderr
     assert os.path.exists(out) and not glob.glob(str(tmp_path / "20*.bmp"))
     done = int(r.stdout.split(" of 100000")[0].split()[-1])
-    assert 0 < done < 100000 and (done - 1) % 50 == 0      # stopped by -TL at a slice boundary
+    assert 0 < done < 100000                                # stopped by -TL (main.cpp:111-114)
+    ms = int(r.stdout.split()[1])                           # elapsed milliseconds in the reference's file-name line
+    assert 1000 <= ms < 1400                                # ... within one ~75 ms slice (+ resolve) of the limit
+
+
+def test_cli_time_limit_without_previews(tmp_path, models_dir):
+    """-UPDATE 0 (one slice for the whole frame without a time limit): -TL must still stop the run in time."""
+    out = str(tmp_path / "y.bmp")
+    r = subprocess.run([EXE, "--W", "256", "--H", "256", "-RPP", "10000000", "-TL", "1", "-UPDATE", "0", "-QUIET", "1",
+                        "-ERR", "-1", "-MODEL_PATH", models_dir, "-OUT", out], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    done = int(r.stdout.split(" of 10000000")[0].split()[-1])
+    ms = int(r.stdout.split()[1])
+    assert 0 < done < 10000000 and 1000 <= ms < 1500

@@ -23,5 +23,8 @@ def test_scene_code_is_clean_under_asan_and_ubsan(tmp_path, models_dir):
     assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr
     out = run.stdout
-    assert "eps 0.0001: 2 clusters" in out and "n 3000:" in out and "3004 bary_all" in out
+    assert "eps 0.0001: 2 clusters" in out and "n 3000:" in out and " bvh" in out
+    import re
+    m = re.search(r"n 3000: \d+ clusters \d+ spheres \d+ bary (\d+) bary_all (\d+) slots (\d+) bvh", out)
+    assert m and int(m.group(1)) == int(m.group(2)) + 4 and int(m.group(2)) >= 3000 and int(m.group(3)) > 300
     assert out.count("bad obj -> 0") == 4 and "bad obj -> 1" in out        # four rejected with a message, the empty file loads (no triangles)
