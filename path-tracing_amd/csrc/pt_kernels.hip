@@ -42,8 +42,15 @@ constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per w
 struct SmallQueues { static constexpr int kNodeStack = 96, kPairQueue = 144, kFiltered = 1; };
 #ifndef PT_BIG_NODES
 #define PT_BIG_NODES 384      // measured on the 16 398- and 49 934-triangle scenes: 832 / 512 (4 waves per SIMD) is 4 % slower,
+#endif
+#ifndef PT_BIG_PAIRS
 #define PT_BIG_PAIRS 256      // 256 / 160 (6 waves per SIMD) 7 % slower than this (5 waves per SIMD)
+#endif
+#ifndef PT_BIG_FILTERED
 #define PT_BIG_FILTERED 128
+#endif
+#ifndef PT_BIG_EXACT_AT
+#define PT_BIG_EXACT_AT 64    // big scenes: pre-filtered pairs waiting before an exact round runs (fewer = earlier pruning, emptier rounds)
 #endif
 struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };
 
@@ -377,26 +384,40 @@ __device__ __forceinline__ float safe_rcp(float d) {
     return __builtin_amdgcn_rcpf(__builtin_copysignf(m, d));
 }
 __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
-                                                      float t_best, float err) {
+                                                      float t_best, float err, uint32_t &far_half) {
     const float step = __uint_as_float((q0.w & 0xFFu) << 23);
     const float ix = safe_rcp(r.dx), iy = safe_rcp(r.dy), iz = safe_rcp(r.dz);
     const float ax = step * ix, ay = step * iy, az = step * iz;
-    const float bx = (__uint_as_float(q0.x) - r.ox) * ix, by = (__uint_as_float(q0.y) - r.oy) * iy, bz = (__uint_as_float(q0.z) - r.oz) * iz;
+    const float ex = __uint_as_float(q0.x) - r.ox, ey = __uint_as_float(q0.y) - r.oy, ez = __uint_as_float(q0.z) - r.oz;
+    const float bx = ex * ix, by = ey * iy, bz = ez * iz;
     const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx), __builtin_fabsf(by)), __builtin_fabsf(bz));
     const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ax), __builtin_fabsf(ay)), __builtin_fabsf(az));
     const float e2 = 2.0f * err * __builtin_fmaf(255.0f, amax, bmax);
-    uint32_t m = 0;
+    // where along the ray the centre of the node's frame is: children entered beyond it are the "far half" (speed only:
+    // the walk expands the near half first, so that hits found there prune the far half)
+    const float hc = 127.5f * step;
+    const float t_mid = __builtin_fmaf(ex + hc, r.dx, __builtin_fmaf(ey + hc, r.dy, (ez + hc) * r.dz));
+    // The ray enters a slab through its lower plane if it travels upwards along that axis, else through the upper one:
+    // pick the byte rows of the entry (n) and exit (f) planes once per node.  A, B and the byte are the same for both, and
+    // q -> fma(A, q, B) is monotone, so entry <= exit per axis holds in float arithmetic too.
+    const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
+    const uint32_t nx0 = sx ? q2.z : q1.x, nx1 = sx ? q2.w : q1.y, fx0 = sx ? q1.x : q2.z, fx1 = sx ? q1.y : q2.w;
+    const uint32_t ny0 = sy ? q3.x : q1.z, ny1 = sy ? q3.y : q1.w, fy0 = sy ? q1.z : q3.x, fy1 = sy ? q1.w : q3.y;
+    const uint32_t nz0 = sz ? q3.z : q2.x, nz1 = sz ? q3.w : q2.y, fz0 = sz ? q2.x : q3.z, fz1 = sz ? q2.y : q3.w;
+    uint32_t m = 0, far = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int k = c & 3;
         const bool up = c >= 4;
-        const float x0 = __builtin_fmaf(ax, byte_to_float(up ? q1.y : q1.x, k), bx), x1 = __builtin_fmaf(ax, byte_to_float(up ? q2.w : q2.z, k), bx);
-        const float y0 = __builtin_fmaf(ay, byte_to_float(up ? q1.w : q1.z, k), by), y1 = __builtin_fmaf(ay, byte_to_float(up ? q3.y : q3.x, k), by);
-        const float z0 = __builtin_fmaf(az, byte_to_float(up ? q2.y : q2.x, k), bz), z1 = __builtin_fmaf(az, byte_to_float(up ? q3.w : q3.z, k), bz);
-        const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
-        const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fminf(__builtin_fmaxf(z0, z1), t_best));
+        const float tnx = __builtin_fmaf(ax, byte_to_float(up ? nx1 : nx0, k), bx), tfx = __builtin_fmaf(ax, byte_to_float(up ? fx1 : fx0, k), bx);
+        const float tny = __builtin_fmaf(ay, byte_to_float(up ? ny1 : ny0, k), by), tfy = __builtin_fmaf(ay, byte_to_float(up ? fy1 : fy0, k), by);
+        const float tnz = __builtin_fmaf(az, byte_to_float(up ? nz1 : nz0, k), bz), tfz = __builtin_fmaf(az, byte_to_float(up ? fz1 : fz0, k), bz);
+        const float t_in = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+        const float t_out = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, t_best));
         m |= !(t_in > t_out + e2) ? (1u << c) : 0u;   // a NaN keeps
+        far |= (t_in > t_mid) ? (1u << c) : 0u;
     }
+    far_half = far;
     return m;
 }
 
@@ -419,8 +440,13 @@ __device__ __noinline__ unsigned long long brute_force_key(const RenderArgs &a, 
 
 template <class Lds, class Stats>
 __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray &q, bool valid, int lane,
-                                            float eps, float &best, int &hit, Stats &st) {
+                                            float eps, float &best, int &hit, const ExactRec *&hit_rec, Stats &st) {
     constexpr uint32_t kNodeStack = Lds::kNodeStack, kPairQueue = Lds::kPairQueue;
+    // Small scenes (at most kBigSceneTriangles = 2048 triangles, so 16 bits each): the closest-hit key carries the SLOT
+    // below the original index, and shading reads the slot-ordered record the exact test has just pulled through the
+    // caches.  Big scenes look the hit up in the table kept in the original order.
+    constexpr bool kPackSlot = !Lds::kPrefilter;
+    static_assert(kBigSceneTriangles < 65536, "packed (original index, slot) key");
     ++st.w_segments;
     PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
     lds.best[lane] = ~0ull;
@@ -445,7 +471,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             uint32_t orig;   // the pair names a SLOT; the closest-hit key carries the original triangle index (tie-break)
             const float nd = exact_inside(a.exact_slot + tri, r, eps, orig);   // -inf unless stages B-D pass
             if (nd >= eps && nd < __builtin_inff())
-                atomicMin(&lds.best[src], (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | orig);
+                atomicMin(&lds.best[src], (static_cast<unsigned long long>(ordered_bits(nd)) << 32) | (kPackSlot ? (orig << 16) | tri : orig));
         }
     };
     auto drain_pairs = [&](uint32_t keep_below) {
@@ -478,9 +504,11 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 if (keep) lds.filtered[n_filtered + lanes_below(ball)] = e;
                 n_filtered += __builtin_popcountll(ball);
                 wave_sync();
-                if (n_filtered >= 64u) {
-                    n_filtered -= 64u;
-                    exact_round(lds.filtered[n_filtered + lane], true, 64u);
+                if (n_filtered >= static_cast<uint32_t>(PT_BIG_EXACT_AT)) {
+                    const uint32_t take = min(64u, n_filtered);
+                    n_filtered -= take;
+                    const bool on = static_cast<uint32_t>(lane) < take;
+                    exact_round(on ? lds.filtered[n_filtered + lane] : 0u, on, take);
                     wave_sync();
                 }
             }
@@ -812,7 +840,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             while (n_nodes > 0) {
                 ++st.w_node_rounds;
                 const uint32_t cnt = min(64u, n_nodes);
-                uint32_t m8 = 0, src = 0, base = 0;
+                uint32_t m8 = 0, src = 0, base = 0, far = 0;
                 bool leaf = false;
                 if (static_cast<uint32_t>(lane) < cnt) {
                     const uint32_t e = lds.nodes[n_nodes - 1 - lane];
@@ -825,7 +853,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     const float t_best = bh == 0xFFFFFFFFu ? __builtin_inff() : from_ordered_bits(bh);
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    m8 = box_children_kept(q0, q1, q2, q3, r, t_best, a.bvh_err);
+                    m8 = box_children_kept(q0, q1, q2, q3, r, t_best, a.bvh_err, far);
                     m8 &= (2u << ((q0.w >> 8) & 7u)) - 1u;   // children that exist
                     leaf = node >= a.bvh_leaf0;
                     base = leaf ? (node - a.bvh_leaf0) * kFan : (q0.w >> 11);
@@ -848,20 +876,30 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 }
                 n_nodes -= keep;
                 wave_sync();
-                uint32_t nb = leaf ? 0u : m8;
-                while (__any(nb != 0)) {
-                    const bool has = nb != 0;
+                // Children go on the stack far half first, and RIGHT-ALIGNED over the (at most 8) push steps: a lane with c
+                // children pushes in the last c steps, so the last step holds every lane's nearest child and the top of the
+                // stack -- the next round -- is the near front of all rays.  The walk then runs depth-first, nearest first,
+                // for the whole wave; leaves (and exact tests) are reached early and their hits prune what is still stacked.
+                uint32_t nb_far = leaf ? 0u : (m8 & far), nb_near = leaf ? 0u : (m8 & ~far);
+                const uint32_t n_kids = __builtin_popcount(nb_far | nb_near);   // not `kids`: a partial commit may have cleared m8
+#pragma unroll 1
+                for (uint32_t it = 8; it-- > 0;) {
+                    const bool has = it < n_kids;
                     const unsigned long long ball = __ballot(has);
+                    if (ball == 0) continue;
                     if (has) {
-                        const uint32_t c8 = __builtin_ctz(nb);
-                        nb &= nb - 1;
+                        uint32_t c8;
+                        if (nb_far != 0) { c8 = __builtin_ctz(nb_far); nb_far &= nb_far - 1; }
+                        else { c8 = __builtin_ctz(nb_near); nb_near &= nb_near - 1; }
                         lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (base + c8);
                     }
                     n_nodes += __builtin_popcountll(ball);
                 }
                 wave_sync();
                 push_pairs(leaf ? m8 : 0u, base, src);
+                PT_STAMP(st, 2);   // box-tree rounds
                 if (n_pairs >= 64u) drain_pairs(63);
+                PT_STAMP(st, 6);   // pre-filter + exact rounds inside the walk
             }
             PT_STAMP(st, 2);
         }
@@ -878,16 +916,19 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     }
     PT_STAMP(st, 5);   // exact rounds
     const unsigned long long key = lds.best[lane];
+    const uint32_t key_lo = static_cast<uint32_t>(key);
+    hit = (key == ~0ull) ? -1 : static_cast<int>(kPackSlot ? key_lo >> 16 : key_lo);
+    hit_rec = kPackSlot ? a.exact_slot + (key_lo & 0xFFFFu) : a.exact + key_lo;   // dereferenced only if hit >= 0
 #ifdef PT_VERIFY_BRUTE
     // Verification build (libpt_verify.so, never the shipped library): Scene::TraceRay's loop as written -- every
     // triangle through Triangle::Intersect for this lane's own ray -- and a comparison of the two closest hits.
     {
         const unsigned long long brute = brute_force_key(a, q, eps);
         st.v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid)));
-        st.v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid && brute != key)));
+        const unsigned long long mine = (key == ~0ull) ? ~0ull : ((key & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(hit));
+        st.v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid && brute != mine)));
     }
 #endif
-    hit = (key == ~0ull) ? -1 : static_cast<int>(key & 0xFFFFFFFFu);
     best = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
     wave_sync();
 }
@@ -1003,7 +1044,8 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
 
             float best;
             int hit;
-            closest_hit(a, lds, q, valid, lane, eps, best, hit, wst);
+            const ExactRec *hit_rec;
+            closest_hit(a, lds, q, valid, lane, eps, best, hit, hit_rec, wst);
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
             if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
@@ -1045,7 +1087,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
                     }
                     depth = mrr;   // MakeInvalid
                 } else {
-                    const ExactRec *__restrict__ rec = a.exact + hit;
+                    const ExactRec *__restrict__ rec = hit_rec;
                     const float4 pl = reinterpret_cast<const float4 *>(rec)[0];
                     const int mi = rec->material;
                     const float px = q.ox + q.dx * best, py = q.oy + q.dy * best, pz = q.oz + q.dz * best;
@@ -1203,8 +1245,9 @@ __global__ __launch_bounds__(kBlock, BIG ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_
                         __builtin_fabsf(d2 - 1.0f) <= 1.0e-5f;
     float best;
     int hit;
+    const ExactRec *hit_rec;
     WaveStats st;
-    closest_hit(a, lds, q, valid && inside, lane, a.eps, best, hit, st);
+    closest_hit(a, lds, q, valid && inside, lane, a.eps, best, hit, hit_rec, st);
     if (__any(valid && !inside)) {
         const unsigned long long key = brute_force_key(a, q, a.eps);
         if (!inside) {

@@ -329,7 +329,32 @@ void partition_groups(std::vector<int> &ids, size_t b, const std::vector<size_t>
         if (g < gm) left += sizes[g];
         total += sizes[g];
     }
-    const GeoLess less{&s, &cen, longest_axis(ids, b, b + total, cen)};
+    // the cut that leaves the two most compact halves: smallest sum of (bounding-sphere radius)^2 x triangles over the
+    // three axes (a ray meets a sphere with probability ~ r^2)
+    int best_axis = longest_axis(ids, b, b + total, cen);
+    if (total <= 4096) {
+        double best_cost = INFINITY;
+        std::vector<int> tmp(ids.begin() + b, ids.begin() + b + total);
+        for (int axis = 0; axis < 3; ++axis) {
+            std::nth_element(tmp.begin(), tmp.begin() + left, tmp.end(), GeoLess{&s, &cen, axis});
+            double cost = 0;
+            for (int half = 0; half < 2; ++half) {
+                const size_t h0 = half ? left : 0, h1 = half ? total : left;
+                std::vector<V3> pts;
+                for (size_t i = h0; i < h1; ++i)
+                    for (int v = 0; v < 3; ++v) {
+                        const float *p = &s.tri[14 * static_cast<size_t>(tmp[i]) + 4 + 3 * v];
+                        pts.push_back({p[0], p[1], p[2]});
+                    }
+                std::sort(pts.begin(), pts.end(), [](const V3 &x, const V3 &y) { return x.x != y.x ? x.x < y.x : x.y != y.y ? x.y < y.y : x.z < y.z; });
+                V3 c; double rad;
+                bounding_sphere(pts, c, rad);
+                cost += rad * rad * static_cast<double>(h1 - h0);
+            }
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; }
+        }
+    }
+    const GeoLess less{&s, &cen, best_axis};
     std::nth_element(ids.begin() + b, ids.begin() + b + left, ids.begin() + b + total, less);
     partition_groups(ids, b, sizes, g0, gm, s, cen);
     partition_groups(ids, b + left, sizes, gm, g1, s, cen);
@@ -412,6 +437,95 @@ void arrange_implicit(std::vector<int> &ids, size_t b, size_t e, const HostScene
         arrange_implicit(ids, at, at + sz, s, cen);
         at += sz;
     }
+}
+
+// Alternative arrangement for small clusters: compact PATCHES instead of axis-aligned cells.  Items (triangles, then
+// groups of 8, then groups of 64, ...) are peeled off from the outside in: the item farthest from the centre of what is
+// left seeds a group, its 7 nearest remaining items join it.  Surfaces (a torus, a sphere) pack tighter this way than
+// under planar cuts.  Reorders ids[b, e); the last group of every level is the partial one, as the implicit tree needs.
+void arrange_patches(std::vector<int> &ids, size_t b, size_t e, const HostScene &s, const std::vector<Centroid> &cen) {
+    struct Item { std::vector<int> tris; double c[3]; };
+    std::vector<Item> items;
+    for (size_t i = b; i < e; ++i) items.push_back({{ids[i]}, {cen[ids[i]].c[0], cen[ids[i]].c[1], cen[ids[i]].c[2]}});
+    const GeoLess less{&s, &cen, 0};
+    while (items.size() > 1) {
+        std::vector<uint8_t> used(items.size(), 0);
+        std::vector<Item> next;
+        size_t left = items.size();
+        while (left > 0) {
+            double m[3] = {0, 0, 0};
+            for (size_t i = 0; i < items.size(); ++i)
+                if (!used[i]) for (int k = 0; k < 3; ++k) m[k] += items[i].c[k] / static_cast<double>(left);
+            auto d2 = [](const double *p, const double *q) { return (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]); };
+            // the seed: farthest from the centre of the remaining items (geometry breaks ties, not the file order)
+            size_t seed = items.size();
+            for (size_t i = 0; i < items.size(); ++i) {
+                if (used[i]) continue;
+                if (seed == items.size()) { seed = i; continue; }
+                const double a = d2(items[i].c, m), z = d2(items[seed].c, m);
+                if (a > z || (a == z && less(items[i].tris[0], items[seed].tris[0]))) seed = i;
+            }
+            const size_t take = std::min<size_t>(kFan, left);
+            // grow the group by the item that enlarges its bounding sphere least (on a curved surface that follows the
+            // curvature -- a half ring of a tube fits a smaller sphere than a flat-looking patch of the same area)
+            std::vector<size_t> member = {seed};
+            used[seed] = 1;
+            auto verts_of = [&](const Item &it, std::vector<V3> &out) {
+                for (int t : it.tris)
+                    for (int v = 0; v < 3; ++v) {
+                        const float *p = &s.tri[14 * static_cast<size_t>(t) + 4 + 3 * v];
+                        out.push_back({p[0], p[1], p[2]});
+                    }
+            };
+            std::vector<V3> pts;
+            verts_of(items[seed], pts);
+            V3 gc; double gr;
+            bounding_sphere(pts, gc, gr);
+            for (size_t k = 1; k < take; ++k) {
+                size_t best = items.size();
+                double best_r = INFINITY;
+                for (size_t i = 0; i < items.size(); ++i) {
+                    if (used[i]) continue;
+                    std::vector<V3> q;
+                    verts_of(items[i], q);
+                    double r = gr;   // Ritter-style growth of (gc, gr) over the candidate's vertices
+                    V3 c = gc;
+                    for (const V3 &p : q) {
+                        const V3 d = sub(p, c);
+                        const double dist = nrm(d);
+                        if (dist > r) {
+                            const double nr = (r + dist) / 2, f = (nr - r) / dist;
+                            c = {c.x + d.x * f, c.y + d.y * f, c.z + d.z * f};
+                            r = nr;
+                        }
+                    }
+                    if (r < best_r || (r == best_r && (best == items.size() || less(items[i].tris[0], items[best].tris[0])))) { best_r = r; best = i; }
+                }
+                used[best] = 1;
+                member.push_back(best);
+                verts_of(items[best], pts);
+                bounding_sphere(pts, gc, gr);
+            }
+            left -= take;
+            Item g;
+            g.c[0] = g.c[1] = g.c[2] = 0;
+            std::sort(member.begin(), member.end(), [&](size_t x, size_t y) { return less(items[x].tris[0], items[y].tris[0]); });
+            for (size_t i : member) {
+                g.tris.insert(g.tris.end(), items[i].tris.begin(), items[i].tris.end());
+                for (int k = 0; k < 3; ++k) g.c[k] += items[i].c[k] / static_cast<double>(member.size());
+            }
+            next.push_back(std::move(g));
+        }
+        // the partial group (if any) was formed last: it already sits at the end.  But a group of full SUBGROUPS must not
+        // follow a partial subgroup inside one parent: partial items can only be the very last item of the level, which
+        // holds because only the last-formed group can contain the (single) partial item... unless the peeling picked it
+        // earlier: move the item with the fewest triangles to the end of its level.
+        size_t small = 0;
+        for (size_t i = 1; i < next.size(); ++i) if (next[i].tris.size() < next[small].tris.size()) small = i;
+        if (next[small].tris.size() < next.back().tris.size()) std::swap(next[small], next.back());
+        items.swap(next);
+    }
+    std::copy(items[0].tris.begin(), items[0].tris.end(), ids.begin() + b);
 }
 
 struct UnionFind {
@@ -700,9 +814,34 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
             for (int k = 0; k < 3; ++k) if (a.first.c[k] != b.first.c[k]) return a.first.c[k] < b.first.c[k];
             return a.second < b.second;
         });
+        // cost of laying the implicit 8-ary sphere tree over an order: sum of r^2 over its nodes (a ray meets a sphere
+        // with probability ~ r^2)
+        auto order_cost = [&](const std::vector<int> &ids) {
+            double cost = 0;
+            const long long n = static_cast<long long>(ids.size());
+            for (long long span = kFan; span * kFan < n * kFan && span < n; span *= kFan)   // levels below the top one
+                for (long long f = 0; f < n; f += span) {
+                    SphereRec sr;
+                    const double reff = sphere_of(&ids[f], static_cast<int>(std::min<long long>(span, n - f)), sr);
+                    cost += std::isfinite(reff) ? reff * reff : 0.0;
+                }
+            return cost;
+        };
         for (const auto &kg : keyed) {
-            std::vector<int> ids = groups[kg.second];
-            arrange_implicit(ids, 0, ids.size(), s, cen);
+            // the cheaper of two spatial arrangements
+            // (two geometry-only arrangements are tried and the cheaper kept; results do not depend on the choice)
+            std::vector<int> ids = groups[kg.second], patches = ids;
+            arrange_implicit(ids, 0, ids.size(), s, cen);          // axis-aligned cells
+            if (patches.size() <= 4096) {                          // compact patches (quadratic in the group size)
+                arrange_patches(patches, 0, patches.size(), s, cen);
+#ifdef PT_TEST_HOOKS
+                if (g_cull_mutation.order_mode == 1) ids = groups[kg.second];   // as filed
+                else if (g_cull_mutation.order_mode == 3) ids = patches;
+                else if (g_cull_mutation.order_mode == 0 && order_cost(patches) < order_cost(ids)) ids = patches;
+#else
+                if (order_cost(patches) < order_cost(ids)) ids = patches;
+#endif
+            }
             small_runs.push_back({static_cast<int>(order.size()), static_cast<int>(ids.size())});
             order.insert(order.end(), ids.begin(), ids.end());
         }

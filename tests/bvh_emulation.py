@@ -36,10 +36,13 @@ def children_kept(t, node, o, d, t_best, err):
     e2 = F(2) * F(err) * fma(np.full(len(node), F(255)), np.abs(a).max(1), np.abs(b).max(1))
     lo = t["lo"][node].astype(np.float32)      # [n, 3, 8]
     hi = t["hi"][node].astype(np.float32)
-    t0 = fma(np.broadcast_to(a[:, :, None], lo.shape), lo, np.broadcast_to(b[:, :, None], lo.shape))
-    t1 = fma(np.broadcast_to(a[:, :, None], hi.shape), hi, np.broadcast_to(b[:, :, None], hi.shape))
-    t_in = np.maximum(np.minimum(t0, t1).max(1), F(0))
-    t_out = np.minimum(np.maximum(t0, t1).min(1), t_best[:, None])
+    # the kernel picks the entry / exit plane of every slab by the sign of the reciprocal direction
+    neg = (inv < 0)[:, :, None]
+    near, far = np.where(neg, hi, lo), np.where(neg, lo, hi)
+    t0 = fma(np.broadcast_to(a[:, :, None], lo.shape), near, np.broadcast_to(b[:, :, None], lo.shape))
+    t1 = fma(np.broadcast_to(a[:, :, None], hi.shape), far, np.broadcast_to(b[:, :, None], hi.shape))
+    t_in = np.maximum(t0.max(1), F(0))
+    t_out = np.minimum(t1.min(1), t_best[:, None])
     keep = ~(t_in > t_out + e2[:, None])
     exists = np.arange(8)[None, :] < t["count"][node][:, None]
     return keep & exists

@@ -25,7 +25,9 @@ import oracle_lib as O  # noqa: E402
 
 pt = importlib.import_module("path-tracing_amd")
 
-FAMILIES = ["sphere_r2", "m0", "k12", "a_max", "quad_slack"]
+# single families, and the barycentric margins together (each of them alone is covered by the others' slack)
+FAMILIES = [("sphere_r2",), ("box",), ("box_err",), ("m0",), ("k12",), ("a_max",), ("quad_slack",), ("m0", "k12", "quad_slack"),
+            ("m0", "k12", "quad_slack", "a_max")]
 LADDER = [1.0, 0.98, 0.9, 0.7, 0.4, 0.1, 0.0]
 
 
@@ -37,7 +39,7 @@ class Workload:
         self.tmp = tempfile.mkdtemp() + "/"
         models = os.path.join(ROOT, "models") + "/"
         M.generate(os.path.join(ROOT, "models"), self.tmp, "x9.obj", 9)
-        self.scenes = [(models, "Tor.obj", (96, 64, 8)), (self.tmp, "x9.obj", (64, 40, 4))]
+        self.scenes = [(models, "Tor.obj", (96, 64, 8)), (self.tmp, "x9.obj", (64, 40, 4))]   # small-scene and box-tree paths
         self.oracle = []
         for d, name, (W, H, spp) in self.scenes:
             o = O.Scene.load(d, name)
@@ -58,11 +60,19 @@ class Workload:
         w = rng.dirichlet([1, 1, 1], n)
         src = (v[a] * w[:, :, None]).sum(1) + nrm[a] * 1e-4
         d = rng.normal(size=(n, 3))
-        # half of them aimed at a point NEAR THE EDGE of another triangle (where a too-small margin bites first)
-        b = rng.integers(0, T, n)
-        e = rng.random((n, 1))
-        tgt = v[b, 0] * e + v[b, 1] * (1 - e) + rng.normal(size=(n, 3)) * 1e-4
-        d = np.where((np.arange(n) % 2 == 0)[:, None], d, tgt - src)
+        # three quarters of them aimed AT an edge or a vertex of another triangle -- exactly on it, or a hair to either
+        # side -- where a margin that is too small bites first; large triangles (walls) are picked as often as small ones
+        area = tri[:, 13].astype(np.float64)
+        big = np.flatnonzero(area > 0.25 * area.max())
+        b = np.where(rng.random(n) < 0.5, big[rng.integers(0, len(big), n)], rng.integers(0, T, n))
+        e = rng.random((n, 1)) * (rng.random((n, 1)) < 0.9)          # 10 %: exactly a vertex
+        k = rng.integers(0, 3, n)
+        p0, p1, p2 = v[b, k], v[b, (k + 1) % 3], v[b, (k + 2) % 3]
+        inward = (p2 - (p0 + p1) / 2)
+        inward /= np.linalg.norm(inward, axis=1, keepdims=True) + 1e-30
+        hair = rng.choice([0.0, 0.0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5], n)[:, None]
+        tgt = p0 * e + p1 * (1 - e) + inward * hair
+        d = np.where((np.arange(n) % 4 == 0)[:, None], d, tgt - src)
         src = src.astype(np.float32)
         d = d.astype(np.float32)
         inv = np.float32(1) / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
@@ -85,12 +95,13 @@ class Workload:
 def main():
     lib = pt.load_library(pt.TESTHOOKS_LIB_PATH)
     w = Workload()
-    for fam in FAMILIES:
+    for fams in FAMILIES:
         for scale in LADDER:
             lib.pt_test_set_mutation(b"reset", 0.0)
-            lib.pt_test_set_mutation(fam.encode(), scale)
+            for fam in fams:
+                lib.pt_test_set_mutation(fam.encode(), scale)
             px, rays = w.run(lib)
-            print(json.dumps({"family": fam, "scale": scale, "differing_pixels": px, "differing_rays": rays}), flush=True)
+            print(json.dumps({"family": "+".join(fams), "scale": scale, "differing_pixels": px, "differing_rays": rays}), flush=True)
     lib.pt_test_set_mutation(b"reset", 0.0)
 
 

@@ -34,8 +34,16 @@ def main():
     for n in (64, 195):
         M.generate(os.path.join(ROOT, "models"), tmp, f"TorX{n}.obj", n)
         scenes[f"TorX{n}.obj"] = (tmp, f"TorX{n}.obj")
+    import shuffle_obj
+    shuffle_obj.shuffle(os.path.join(ROOT, "models", "Tor.obj"), tmp + "TorShuffled.obj")
+    scenes["TorShuffled.obj"] = (tmp, "TorShuffled.obj")
+    shuffle_obj.shuffle(tmp + "TorX64.obj", tmp + "TorX64Shuffled.obj")
+    scenes["TorX64Shuffled.obj"] = (tmp, "TorX64Shuffled.obj")
     configs = [
         ("1", "Tor.obj", 256, 256, 4, 3, -1.0),
+        ("2-256spp", "Tor.obj", 1920, 1080, 256, 8, -1.0),
+        ("2-256spp-shuffled-faces", "TorShuffled.obj", 1920, 1080, 256, 8, -1.0),
+        ("5-x64-shuffled-faces", "TorX64Shuffled.obj", 1920, 1080, 256, 8, -1.0),
         ("2", "Tor.obj", 1920, 1080, 64, 8, -1.0),
         ("2-adaptive", "Tor.obj", 1920, 1080, 64, 8, 0.001),
         ("3", "Tor.obj", 1920, 1080, 1024, 8, -1.0),
@@ -71,6 +79,9 @@ def main():
                "traced_samples": st["samples_traced"], "traced_Msamples_per_s": round(st["samples_traced"] / ms / 1e3, 1),
                "segments_per_sample": round(st["segments"] / max(1, st["samples_traced"]), 3),
                "exact_tests_per_segment": round(st["exact_tests"] / max(1, st["segments"]), 3),
+               "node_rounds_per_wave_segment": round(st["wave_node_rounds"] / max(1, st["wave_segments"]), 2),
+               "exact_rounds_per_wave_segment": round(st["wave_exact_iterations"] / max(1, st["wave_segments"]), 2),
+               "partial_commit_rounds": st["partial_commit_rounds"],
                "contributing_fraction": round(st["contributing"] / max(1, st["samples_traced"]), 5)}
         print(json.dumps(out), flush=True)
         sc.close()
