@@ -131,9 +131,9 @@ void pt_scene_destroy(pt_scene *scene);
 int pt_render_device(pt_scene *scene, const pt_render_params *params, float *d_sum, float *d_sum2,
                      int32_t *d_count, void *hip_stream, pt_render_stats *stats);
 
-/* Same, with HOST buffers (PCIe-inclusive convenience path).  The band is cut into row slabs that are staged through
- * pinned memory and uploaded / rendered / downloaded on three streams, so the transfers overlap the kernel; device
- * and staging buffers are kept by the scene between calls. */
+/* Same, with HOST buffers (PCIe-inclusive convenience path): upload, one launch, download; the device band is kept by
+ * the scene between calls.  A driver that adds many pass slices to one frame should use a pt_session instead, which
+ * moves the accumulators only when it is read. */
 int pt_render_host(pt_scene *scene, const pt_render_params *params, float *sum, float *sum2, int32_t *count,
                    pt_render_stats *stats);
 

@@ -55,7 +55,6 @@ struct pt_scene {
     float *d_host_band = nullptr;
     size_t host_band_floats = 0;
     hipStream_t host_stream = nullptr;
-    hipEvent_t host_ev[2] = {nullptr, nullptr};
     hipEvent_t ev_done = nullptr;
     bool has_prev = false;
     hipStream_t prev_stream = nullptr;
@@ -365,7 +364,6 @@ void pt_scene_destroy(pt_scene *s) {
         if (s->d_sched) (void)hipFree(s->d_sched);
         if (s->d_host_band) (void)hipFree(s->d_host_band);
         if (s->host_stream) (void)hipStreamDestroy(s->host_stream);
-        for (hipEvent_t e : s->host_ev) if (e) (void)hipEventDestroy(e);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
         if (s->ev_done) (void)hipEventDestroy(s->ev_done);
@@ -502,34 +500,6 @@ static int trace_rays_host_impl(pt_scene *scene, int32_t n_rays, const float *or
     return result;
 }
 
-// Row slabs of a band for the host-buffer path: short at both ends (what cannot overlap is the first upload and the
-// last download), long in the middle.
-static std::vector<int> slab_rows(int rows, int width) {
-    const int tile = pt::kTileH;
-    int cap = static_cast<int>((24u << 20) / (static_cast<size_t>(width) * 28u)) / tile * tile;   // about 24 MB per slab
-    cap = std::max(tile, cap);
-    std::vector<int> front, back;
-    int left = rows;
-    for (int r = 2 * tile; left > 0 && r <= cap; r *= 2) {
-        if (left > 3 * r) {
-            front.push_back(r);
-            back.push_back(r);
-            left -= 2 * r;
-        } else {
-            break;
-        }
-    }
-    const int mid = (left + cap - 1) / cap;
-    for (int k = 0; k < mid; ++k) {
-        int r = (left / (mid - k) + tile - 1) / tile * tile;
-        r = std::min(r, left);
-        front.push_back(r);
-        left -= r;
-    }
-    front.insert(front.end(), back.rbegin(), back.rend());
-    return front;
-}
-
 static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *sum, float *sum2, int32_t *count,
                    pt_render_stats *stats) {
     const int rc = check_params(scene, p);
@@ -538,11 +508,13 @@ static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *s
     PT_HIP_TRY(hipSetDevice(scene->device));
     const int rows = p->row_end - p->row_begin;
     const size_t W = static_cast<size_t>(p->width), n = static_cast<size_t>(rows) * W;
-    if (stats) {
-        std::memset(stats, 0, sizeof *stats);
-        stats->n_triangles = scene->host.n_tri();
+    if (n == 0) {
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+            stats->n_triangles = scene->host.n_tri();
+        }
+        return PT_OK;
     }
-    if (n == 0) return PT_OK;
     std::lock_guard<std::mutex> host_lock(scene->host_mutex);
     // device band (sum | sum2 | count planes, 256-byte aligned planes), grown on demand and kept
     const size_t plane = (3 * n + 63) / 64 * 64;
@@ -553,58 +525,24 @@ static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *s
         PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scene->d_host_band), (2 * plane + n) * sizeof(float) + 256));
         scene->host_band_floats = 2 * plane + n;
     }
-    if (!scene->host_stream) {
-        PT_HIP_TRY(hipStreamCreateWithFlags(&scene->host_stream, hipStreamNonBlocking));
-        for (hipEvent_t &e : scene->host_ev) PT_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    if (!scene->host_stream) PT_HIP_TRY(hipStreamCreateWithFlags(&scene->host_stream, hipStreamNonBlocking));
     float *d_sum = scene->d_host_band, *d_sum2 = d_sum + plane;
     int32_t *d_count = reinterpret_cast<int32_t *>(d_sum2 + plane);
-    // Slab pipeline.  The copies are plain synchronous hipMemcpy calls on the caller's pageable buffers (the runtime's
-    // fastest path for them); the kernels run on a non-blocking stream of their own, so the upload of slab i + 1 and the
-    // download of slab i - 1 proceed while slab i renders.  Pixels are independent and the random numbers are keyed by
-    // the global pixel index, so slabs change nothing in the result (tests: row bands == full frame).
-    const std::vector<int> slabs = slab_rows(rows, p->width);
-    struct Pending { int row0, nrows; bool live; } prev = {0, 0, false};
-    auto download = [&](const Pending &s) -> int {
-        const size_t off = static_cast<size_t>(s.row0) * W, cnt = static_cast<size_t>(s.nrows) * W;
-        PT_HIP_TRY(hipMemcpy(sum + 3 * off, d_sum + 3 * off, cnt * 12, hipMemcpyDeviceToHost));
-        PT_HIP_TRY(hipMemcpy(sum2 + 3 * off, d_sum2 + 3 * off, cnt * 12, hipMemcpyDeviceToHost));
-        PT_HIP_TRY(hipMemcpy(count + off, d_count + off, cnt * 4, hipMemcpyDeviceToHost));
-        return PT_OK;
-    };
-    int row0 = 0, k = 0;
-    for (int nrows : slabs) {
-        const size_t off = static_cast<size_t>(row0) * W, cnt = static_cast<size_t>(nrows) * W;
-        PT_HIP_TRY(hipMemcpy(d_sum + 3 * off, sum + 3 * off, cnt * 12, hipMemcpyHostToDevice));
-        PT_HIP_TRY(hipMemcpy(d_sum2 + 3 * off, sum2 + 3 * off, cnt * 12, hipMemcpyHostToDevice));
-        PT_HIP_TRY(hipMemcpy(d_count + off, count + off, cnt * 4, hipMemcpyHostToDevice));
-        pt_render_params sp = *p;
-        sp.row_begin = p->row_begin + row0;
-        sp.row_end = sp.row_begin + nrows;
-        pt_render_stats st;
-        const int r = render_device_impl(scene, &sp, d_sum + 3 * off, d_sum2 + 3 * off, d_count + off, scene->host_stream, stats ? &st : nullptr);
-        if (r != PT_OK) return r;
-        if (stats) {
-            stats->samples_traced += st.samples_traced; stats->segments += st.segments; stats->contributing += st.contributing;
-            stats->exact_tests += st.exact_tests; stats->misses += st.misses; stats->wave_segments += st.wave_segments;
-            stats->wave_node_rounds += st.wave_node_rounds; stats->wave_exact_iterations += st.wave_exact_iterations;
-            stats->kernel_ms += st.kernel_ms;
-            stats->n_chunks = std::max(stats->n_chunks, st.n_chunks);
-            stats->partial_commit_rounds += st.partial_commit_rounds;
-            stats->verify_checked += st.verify_checked; stats->verify_mismatches += st.verify_mismatches;
-        }
-        PT_HIP_TRY(hipEventRecord(scene->host_ev[k & 1], scene->host_stream));
-        if (prev.live) {   // slab i - 1: wait for its kernel (slab i is already queued behind it), then bring it home
-            PT_HIP_TRY(hipEventSynchronize(scene->host_ev[(k - 1) & 1]));
-            const int d = download(prev);
-            if (d != PT_OK) return d;
-        }
-        prev = {row0, nrows, true};
-        row0 += nrows;
-        ++k;
-    }
-    PT_HIP_TRY(hipEventSynchronize(scene->host_ev[(k - 1) & 1]));
-    return download(prev);
+    // One launch for the whole band between plain synchronous copies.  (Measured and dropped: cutting the band into row
+    // slabs so that copies overlap kernels.  A tile's passes run strictly in order, so every launch lasts at least one
+    // tile's whole pass chain -- 13.6 ms at 256 spp whatever the slab's height -- and ten slabs took 189 ms where one
+    // launch takes 96 ms + 3.4 ms of copies; profiles/r02_host_path_slabs.txt.  hipMemcpyAsync into pageable memory ran
+    // at about 1 GB/s here, the synchronous call at PCIe speed.)
+    PT_HIP_TRY(hipMemcpy(d_sum, sum, n * 12, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(d_sum2, sum2, n * 12, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(d_count, count, n * 4, hipMemcpyHostToDevice));
+    const int r = render_device_impl(scene, p, d_sum, d_sum2, d_count, scene->host_stream, stats);
+    if (r != PT_OK) return r;
+    PT_HIP_TRY(hipStreamSynchronize(scene->host_stream));
+    PT_HIP_TRY(hipMemcpy(sum, d_sum, n * 12, hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(sum2, d_sum2, n * 12, hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(count, d_count, n * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
 }
 
 static int session_create_impl(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, pt_session **out) {

@@ -237,7 +237,7 @@ TriGeo tri_geometry(const float *r, double eps) {
     const double perim = nrm(e1) + nrm(e2) + nrm(e3);
     // float error of the reference's |S - s1 - s2 - s3| for a point near the triangle: three cross products of
     // vectors no longer than ~diam, three lengths, three subtractions
-    const double e_fp = 40.0 * kU * (g.diam + 1e-3) * (g.diam + 1e-3);
+    const double e_fp = 48.0 * kU * (g.diam + 1e-3) * (g.diam + 1e-3);   // first-order worst case 37 u, largest seen 32 u (tests/test_cull_margins_host.py)
     const double big_e = std::fabs(eps) + e_fp;
     // A triangle whose area is within a few eps of zero is accepted by the reference for points that have nothing to
     // do with it (all three computed sub-areas can vanish far away): never cull it.
@@ -549,7 +549,7 @@ const Box kEmptyBox = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -I
 // P* = o + d t* (eps_line).
 Box acceptance_box(const TriGeo &g, double eps_line) {
     Box b = kEmptyBox;
-    const double m = g.m_geo * PT_MUT(box);
+    const double m = g.m_geo;
     for (int k = 0; k < 3; ++k) {
         const V3 &v = g.v[k], &a = g.v[(k + 1) % 3], &c = g.v[(k + 2) % 3];
         const double p[3] = {v.x + m * (2 * v.x - a.x - c.x), v.y + m * (2 * v.y - a.y - c.y), v.z + m * (2 * v.z - a.z - c.z)};
@@ -559,9 +559,15 @@ Box acceptance_box(const TriGeo &g, double eps_line) {
     const double len = nrm(nn);
     const double n[3] = {std::fabs(nn.x) / len, std::fabs(nn.y) / len, std::fabs(nn.z) / len};
     for (int x = 0; x < 3; ++x) {
-        const double pad = (g.h_max * n[x] * (1.0 + 1e-9) + eps_line) * PT_MUT(box);
+        const double pad = g.h_max * n[x] * (1.0 + 1e-9) + eps_line;
         b.lo[x] -= pad;
         b.hi[x] += pad;
+#ifdef PT_TEST_HOOKS
+        // mutation testing: scale the box about its centre (1 = as shipped)
+        const double c = 0.5 * (b.lo[x] + b.hi[x]), h = 0.5 * (b.hi[x] - b.lo[x]) * g_cull_mutation.box;
+        b.lo[x] = c - h;
+        b.hi[x] = c + h;
+#endif
     }
     return b;
 }
@@ -1093,7 +1099,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     cc.k2 = static_cast<float>(PT_MUT(k12) * (12.0 * kU * m_abs + 8.0 * kU * r_org));
     cc.k1 = static_cast<float>(PT_MUT(k12) * 40.0 * kU);
     cc.a_max = static_cast<float>(PT_MUT(a_max) * a_max * (1.0 + 1e-6));
-    cc.m0 = static_cast<float>(PT_MUT(m0) * (std::fabs(eps) * inv_2s_max * 1.01 + 40.0 * kU * diam2_2s_max
+    cc.m0 = static_cast<float>(PT_MUT(m0) * (std::fabs(eps) * inv_2s_max * 1.01 + 48.0 * kU * diam2_2s_max
                                              + 16.0 * kU * a_max * r_org * std::sqrt(3.0) + 1e-6));
     double tg = 4096.0 * r_org;
     if (a_max > 0) tg = std::min(tg, 1.0e6 / a_max);   // keep the reference's own area arithmetic meaningful
@@ -1102,7 +1108,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     // the same margins over ALL triangles (pair pre-filter of big scenes)
     out.cc_all = cc;
     out.cc_all.a_max = static_cast<float>(PT_MUT(a_max) * a_max_all * (1.0 + 1e-6));
-    out.cc_all.m0 = static_cast<float>(PT_MUT(m0) * (std::fabs(eps) * inv_2s_max_all * 1.01 + 40.0 * kU * diam2_2s_max_all
+    out.cc_all.m0 = static_cast<float>(PT_MUT(m0) * (std::fabs(eps) * inv_2s_max_all * 1.01 + 48.0 * kU * diam2_2s_max_all
                                                      + 16.0 * kU * a_max_all * r_org * std::sqrt(3.0) + 1e-6));
     double tga = 4096.0 * r_org;
     if (a_max_all > 0) tga = std::min(tga, 1.0e6 / a_max_all);
