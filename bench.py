@@ -242,6 +242,7 @@ def main():
                     help="hardware counters of the timed kernel: collected now with rocprofv3 in child processes (N = 1), read "
                          "from a committed summary of the same kernel source, or omitted")
     ap.add_argument("--no-configs3", action="store_true", help="skip the 3840x2160 x 256 spp strong-scaling leg")
+    ap.add_argument("--save-pmc", default="", help="write the live counters as a summary `--pmc file` can read later (profiles/rNN_pmc_hbm.json)")
     ap.add_argument("--write-bmp", default="", help="resolve rank 0's gathered frame and write it here")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all render on device 0 and gather over gloo (host copies): exercises the multi-rank "
@@ -400,6 +401,12 @@ def main():
                 # KiB -> bytes.  The guide's x2 on FETCH_SIZE is for wide streaming reads; this kernel's reads are 4-byte
                 # strided accumulator loads, calibrated 0.76-1.0 : 1 on their known byte count
                 traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        if args.save_pmc and pmc and pmc_source.startswith("rocprofv3"):
+            json.dump({"kernel": "pt::integrate_kernel<false,false,false>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
+                       "kernel_source_sha": kernel_source_sha(), "kernel_ms": kms, "counters_per_launch": pmc,
+                       "collected_by": "bench.py --save-pmc: " + pmc_source,
+                       "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes; SQ_INSTS_VALU counts wave-instructions"},
+                      open(args.save_pmc, "w"), indent=1)
         achieved = lane_ops / (kms * 1e-3) / 1e12 if lane_ops and kms > 0 else None
         ref_eq = seg * n_tri * FLOP_PER_TEST / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out = {

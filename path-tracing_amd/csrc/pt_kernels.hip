@@ -373,9 +373,9 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
 // Box tree of big scenes (pt_scene.hpp: BvhNode): which of a node's (up to 8) children can hold a hit of ray r that
 // beats t_best?  Slab test against the 8-bit child boxes, dequantised on the fly: along axis x the planes of child c are
 // t = (org.x + q step - o.x) / d.x = A q + B with A = step / d.x, B = (org.x - o.x) / d.x, one fma per plane.
-// CONSERVATIVE: every computed t is within E = err (|B| + 255 |A|) of its exact value (rcp 1 ulp, one product, one fma:
-// < 3e-7 relative to the operands' magnitudes; err = 4e-7), the boxes were rounded outward on the host, and a child is
-// dropped only if its interval misses [0, t_best] by more than 2E.  A zero direction component is replaced by 1e-30 of
+// CONSERVATIVE: every computed t is within E = err (|B| + 255 |A|) of its exact value (rcp 1 ulp, one product, the
+// subtraction of the allowance, one fma: < 3.6e-7 relative to the operands' magnitudes; err = 5e-7), the boxes were
+// rounded outward on the host, and a child is dropped only if its interval misses [0, t_best] by more than 2E.  A zero direction component is replaced by 1e-30 of
 // the same sign: the ray then misses a slab it starts outside of by an astronomically large t and spans one it starts in.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return static_cast<float>((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
@@ -384,40 +384,35 @@ __device__ __forceinline__ float safe_rcp(float d) {
     return __builtin_amdgcn_rcpf(__builtin_copysignf(m, d));
 }
 __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
-                                                      float t_best, float err, uint32_t &far_half) {
+                                                      float t_best, float err) {
     const float step = __uint_as_float((q0.w & 0xFFu) << 23);
     const float ix = safe_rcp(r.dx), iy = safe_rcp(r.dy), iz = safe_rcp(r.dz);
     const float ax = step * ix, ay = step * iy, az = step * iz;
-    const float ex = __uint_as_float(q0.x) - r.ox, ey = __uint_as_float(q0.y) - r.oy, ez = __uint_as_float(q0.z) - r.oz;
-    const float bx = ex * ix, by = ey * iy, bz = ez * iz;
+    const float bx = (__uint_as_float(q0.x) - r.ox) * ix, by = (__uint_as_float(q0.y) - r.oy) * iy, bz = (__uint_as_float(q0.z) - r.oz) * iz;
     const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx), __builtin_fabsf(by)), __builtin_fabsf(bz));
     const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ax), __builtin_fabsf(ay)), __builtin_fabsf(az));
     const float e2 = 2.0f * err * __builtin_fmaf(255.0f, amax, bmax);
-    // where along the ray the centre of the node's frame is: children entered beyond it are the "far half" (speed only:
-    // the walk expands the near half first, so that hits found there prune the far half)
-    const float hc = 127.5f * step;
-    const float t_mid = __builtin_fmaf(ex + hc, r.dx, __builtin_fmaf(ey + hc, r.dy, (ez + hc) * r.dz));
+    // The allowance goes into the ENTRY planes once per node (entry - 2E against exit) instead of into every comparison.
+    const float nbx = bx - e2, nby = by - e2, nbz = bz - e2, t_min = -e2;
     // The ray enters a slab through its lower plane if it travels upwards along that axis, else through the upper one:
-    // pick the byte rows of the entry (n) and exit (f) planes once per node.  A, B and the byte are the same for both, and
-    // q -> fma(A, q, B) is monotone, so entry <= exit per axis holds in float arithmetic too.
+    // pick the byte rows of the entry (n) and exit (f) planes once per node.  q -> fma(A, q, B) is monotone, so
+    // entry <= exit per axis holds in float arithmetic too.
     const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
     const uint32_t nx0 = sx ? q2.z : q1.x, nx1 = sx ? q2.w : q1.y, fx0 = sx ? q1.x : q2.z, fx1 = sx ? q1.y : q2.w;
     const uint32_t ny0 = sy ? q3.x : q1.z, ny1 = sy ? q3.y : q1.w, fy0 = sy ? q1.z : q3.x, fy1 = sy ? q1.w : q3.y;
     const uint32_t nz0 = sz ? q3.z : q2.x, nz1 = sz ? q3.w : q2.y, fz0 = sz ? q2.x : q3.z, fz1 = sz ? q2.y : q3.w;
-    uint32_t m = 0, far = 0;
+    uint32_t m = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int k = c & 3;
         const bool up = c >= 4;
-        const float tnx = __builtin_fmaf(ax, byte_to_float(up ? nx1 : nx0, k), bx), tfx = __builtin_fmaf(ax, byte_to_float(up ? fx1 : fx0, k), bx);
-        const float tny = __builtin_fmaf(ay, byte_to_float(up ? ny1 : ny0, k), by), tfy = __builtin_fmaf(ay, byte_to_float(up ? fy1 : fy0, k), by);
-        const float tnz = __builtin_fmaf(az, byte_to_float(up ? nz1 : nz0, k), bz), tfz = __builtin_fmaf(az, byte_to_float(up ? fz1 : fz0, k), bz);
-        const float t_in = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+        const float tnx = __builtin_fmaf(ax, byte_to_float(up ? nx1 : nx0, k), nbx), tfx = __builtin_fmaf(ax, byte_to_float(up ? fx1 : fx0, k), bx);
+        const float tny = __builtin_fmaf(ay, byte_to_float(up ? ny1 : ny0, k), nby), tfy = __builtin_fmaf(ay, byte_to_float(up ? fy1 : fy0, k), by);
+        const float tnz = __builtin_fmaf(az, byte_to_float(up ? nz1 : nz0, k), nbz), tfz = __builtin_fmaf(az, byte_to_float(up ? fz1 : fz0, k), bz);
+        const float t_in = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, t_min));
         const float t_out = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, t_best));
-        m |= !(t_in > t_out + e2) ? (1u << c) : 0u;   // a NaN keeps
-        far |= (t_in > t_mid) ? (1u << c) : 0u;
+        m |= !(t_in > t_out) ? (1u << c) : 0u;   // a NaN keeps
     }
-    far_half = far;
     return m;
 }
 
@@ -840,7 +835,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             while (n_nodes > 0) {
                 ++st.w_node_rounds;
                 const uint32_t cnt = min(64u, n_nodes);
-                uint32_t m8 = 0, src = 0, base = 0, far = 0;
+                uint32_t m8 = 0, src = 0, base = 0;
                 bool leaf = false;
                 if (static_cast<uint32_t>(lane) < cnt) {
                     const uint32_t e = lds.nodes[n_nodes - 1 - lane];
@@ -853,16 +848,23 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     const float t_best = bh == 0xFFFFFFFFu ? __builtin_inff() : from_ordered_bits(bh);
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    m8 = box_children_kept(q0, q1, q2, q3, r, t_best, a.bvh_err, far);
+                    m8 = box_children_kept(q0, q1, q2, q3, r, t_best, a.bvh_err);
                     m8 &= (2u << ((q0.w >> 8) & 7u)) - 1u;   // children that exist
                     leaf = node >= a.bvh_leaf0;
                     base = leaf ? (node - a.bvh_leaf0) * kFan : (q0.w >> 11);
                 }
                 const uint32_t kids = __builtin_popcount(m8);
                 uint32_t keep = cnt;
-                const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = wave_sum(leaf ? 0u : kids, 4);
-                if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
-                if (!(n_pairs + tot_tri <= kPairQueue && n_nodes - cnt + tot_node <= kNodeStack)) {
+                // room for everything?  One sum of all children decides in the common case; the split into leaves' triangles and
+                // inner nodes' children is only worked out when that is not enough.
+                const uint32_t tot_all = wave_sum(kids, 4);
+                bool fits_all = n_pairs + tot_all <= kPairQueue && n_nodes - cnt + tot_all <= kNodeStack;
+                if (!fits_all) {
+                    const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = tot_all - tot_tri;
+                    if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
+                    fits_all = n_pairs + tot_tri <= kPairQueue && n_nodes - cnt + tot_node <= kNodeStack;
+                }
+                if (!fits_all) {
                     // Rare: not everything fits.  Commit the longest prefix of lanes (= the top of the stack) whose children do;
                     // the top item always commits (its children are one level deeper; the 64 slots of slack absorb them).
                     const uint32_t it = wave_inclusive_scan(leaf ? kids : 0u, lane), in = wave_inclusive_scan(leaf ? 0u : kids, lane);
@@ -876,21 +878,17 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 }
                 n_nodes -= keep;
                 wave_sync();
-                // Children go on the stack far half first, and RIGHT-ALIGNED over the (at most 8) push steps: a lane with c
-                // children pushes in the last c steps, so the last step holds every lane's nearest child and the top of the
-                // stack -- the next round -- is the near front of all rays.  The walk then runs depth-first, nearest first,
-                // for the whole wave; leaves (and exact tests) are reached early and their hits prune what is still stacked.
-                uint32_t nb_far = leaf ? 0u : (m8 & far), nb_near = leaf ? 0u : (m8 & ~far);
-                const uint32_t n_kids = __builtin_popcount(nb_far | nb_near);   // not `kids`: a partial commit may have cleared m8
-#pragma unroll 1
-                for (uint32_t it = 8; it-- > 0;) {
-                    const bool has = it < n_kids;
+                // (Measured and dropped: pushing the children of the far half of a node first, right-aligned over the push steps so
+                // that the next round is the near front of all rays.  Pruning is already within 10 % of what knowing the final hit
+                // from the start would give -- the walls are tested first and pairs as soon as 64 wait -- and the ordering's 25
+                // instructions per round cost as much as it saved.)
+                uint32_t nb = leaf ? 0u : m8;
+                while (__any(nb != 0)) {
+                    const bool has = nb != 0;
                     const unsigned long long ball = __ballot(has);
-                    if (ball == 0) continue;
                     if (has) {
-                        uint32_t c8;
-                        if (nb_far != 0) { c8 = __builtin_ctz(nb_far); nb_far &= nb_far - 1; }
-                        else { c8 = __builtin_ctz(nb_near); nb_near &= nb_near - 1; }
+                        const uint32_t c8 = __builtin_ctz(nb);
+                        nb &= nb - 1;
                         lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (base + c8);
                     }
                     n_nodes += __builtin_popcountll(ball);

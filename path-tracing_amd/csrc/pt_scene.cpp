@@ -579,7 +579,7 @@ void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::ve
                double eps_line, CullTables &out, std::vector<int> &order) {
     out.bvh.clear();
     out.bvh_leaf0 = 0;
-    out.bvh_err = static_cast<float>(4.0e-7 * PT_MUT(box_err));
+    out.bvh_err = static_cast<float>(5.0e-7 * PT_MUT(box_err));   // first-order worst case 3.6e-7 (tests/test_cull_margins_host.py)
     const size_t n = ids.size();
     if (n == 0) return;
     std::vector<VBox> tbox(geo.size());
@@ -603,7 +603,13 @@ void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::ve
             // as many children as keeps them about three quarters full (room for the cuts to follow the scene's objects),
             // never fewer than the capacity demands
             const size_t cnt = r.e - r.b, k_min = (cnt + cap - 1) / cap;
-            const size_t k = std::min<size_t>(std::min<size_t>(kFan, cnt), std::max(k_min, (4 * cnt + 3 * cap - 1) / (3 * cap)));
+#ifdef PT_TEST_HOOKS
+            const double fill = g_cull_mutation.bvh_fill;
+#else
+            const double fill = 0.75;
+#endif
+            const size_t k_want = static_cast<size_t>(std::ceil(static_cast<double>(cnt) / (fill * static_cast<double>(cap))));
+            const size_t k = std::min<size_t>(std::min<size_t>(kFan, cnt), std::max(k_min, k_want));
             std::vector<size_t> sizes;
             split_sah(ids, r.b, r.e, k, cap, s, cen, tbox, sizes);
             child_base[L].push_back(static_cast<uint32_t>(levels[L - 1].size()));

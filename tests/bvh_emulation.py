@@ -39,11 +39,12 @@ def children_kept(t, node, o, d, t_best, err):
     # the kernel picks the entry / exit plane of every slab by the sign of the reciprocal direction
     neg = (inv < 0)[:, :, None]
     near, far = np.where(neg, hi, lo), np.where(neg, lo, hi)
-    t0 = fma(np.broadcast_to(a[:, :, None], lo.shape), near, np.broadcast_to(b[:, :, None], lo.shape))
+    nb = (b - e2[:, None]).astype(np.float32)      # the allowance goes into the entry planes, once per node
+    t0 = fma(np.broadcast_to(a[:, :, None], lo.shape), near, np.broadcast_to(nb[:, :, None], lo.shape))
     t1 = fma(np.broadcast_to(a[:, :, None], hi.shape), far, np.broadcast_to(b[:, :, None], hi.shape))
-    t_in = np.maximum(t0.max(1), F(0))
+    t_in = np.maximum(t0.max(1), -e2[:, None])
     t_out = np.minimum(t1.min(1), t_best[:, None])
-    keep = ~(t_in > t_out + e2[:, None])
+    keep = ~(t_in > t_out)
     exists = np.arange(8)[None, :] < t["count"][node][:, None]
     return keep & exists
 

@@ -6,7 +6,7 @@ of the code it bounds, against float64 on the SAME float32 inputs.  CPU only.
     eps_line  = 8 u (d_max + r_org)  rounding of P* = o + d t* per component                               (triangles.h:55)
     disc_err  = 24 u d_max^2         error of the kernel's |m|^2 - (m.d)^2                                 (pt_kernels.hip: sphere_keep)
     k1, k2                           |t_cull - t_reference| <= (k2 + k1 |t|) / |n.d|                        (cull_reject)
-    bvh_err   = 4e-7                 |computed slab t - exact slab t| <= bvh_err (|B| + 255 |A|)            (box_children_kept)
+    bvh_err   = 5e-7                 |computed slab t - exact slab t| <= bvh_err (|B| + 255 |A|)            (box_children_kept)
     m0, a_max                        a point the reference accepts has every barycentric >= -(m0 + a_max e_t), random walls
 
 u = 2^-24.  Every check reports how much of the bound the worst sample used, so a margin that is merely lucky shows up.
@@ -144,7 +144,8 @@ def test_plane_distance_error_is_within_k1_k2():
 
 def test_slab_arithmetic_error_is_within_bvh_err():
     """box_children_kept: t = fma(A, q, B), A = step * rcp(d), B = (org - o) * rcp(d) against the exact
-    (org + q step - o) / d: |error| <= bvh_err (|B| + 255 |A|) with bvh_err = 4e-7 (rcp given a full ulp)."""
+    (org + q step - o) / d: |error| <= bvh_err (|B| + 255 |A|) with bvh_err = 5e-7 (rcp given a full ulp); the entry
+    planes use B - 2E (the allowance subtracted once per node), whose rounding is part of the same budget."""
     rng = np.random.default_rng(5)
     n = 400_000
     org = f32(rng.uniform(-21, 21, n))
@@ -159,10 +160,12 @@ def test_slab_arithmetic_error_is_within_bvh_err():
         inv = np.nextafter(inv, np.where(ulp > 0, np.inf, -np.inf).astype(np.float32)) if ulp else inv
         A = (step * inv).astype(np.float32)
         B = ((org - o).astype(np.float32) * inv).astype(np.float32)
-        got = fma32(A, q, B).astype(np.float64)
         ref = (org.astype(np.float64) + q.astype(np.float64) * step.astype(np.float64) - o.astype(np.float64)) / d.astype(np.float64)
-        bound = 4e-7 * (np.abs(B.astype(np.float64)) + 255 * np.abs(A.astype(np.float64)))
-        worst = max(worst, float((np.abs(got - ref) / bound).max()))
+        bound = 5e-7 * (np.abs(B.astype(np.float64)) + 255 * np.abs(A.astype(np.float64)))
+        e2 = (F(2) * F(5e-7) * fma32(np.full(n, F(255)), np.abs(A), np.abs(B))).astype(np.float32)
+        got_exit = fma32(A, q, B).astype(np.float64)
+        got_entry = fma32(A, q, (B - e2).astype(np.float32)).astype(np.float64) + e2.astype(np.float64)   # entry plane, allowance added back
+        worst = max(worst, float((np.abs(got_exit - ref) / bound).max()), float((np.abs(got_entry - ref) / bound).max()))
     print("bvh_err: worst sample uses", worst, "of the bound")
     assert worst < 1.0
 

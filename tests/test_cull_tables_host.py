@@ -273,7 +273,7 @@ def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path):
     node, child = fl + sl // 8, sl % 8
     levels = 0
     while len(node):
-        kept = B.children_kept(t, node, ro, rd, tb, 4e-7)
+        kept = B.children_kept(t, node, ro, rd, tb, 5e-7)
         assert kept[np.arange(len(node)), child].all(), f"a node of level {levels} above a hit was dropped"
         child, node = pos[node], par[node]
         live = node >= 0

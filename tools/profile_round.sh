@@ -1,29 +1,38 @@
 #!/bin/bash
-# Refreshes the round's evidence in ONE gpurun call:  gpurun --timeout 900 -- 'bash tools/profile_round.sh r01'
-#   gpurun_out/bench_1gpu.json        default bench.py run (3 steps, CPU baseline, accuracy)
-#   gpurun_out/prof_kt                rocprofv3 --kernel-trace --stats of the same command (CPU leg skipped)
-#   gpurun_out/prof_{fetch,write,sq1,sq2,sq3}   one --pmc pass each (never combined with a trace domain)
-# then tools/summarize_pmc.py turns them into profiles/<tag>_kernel_stats.csv and profiles/<tag>_pmc_hbm.json.
+# Refreshes the round's evidence in ONE gpurun call:  gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
+# Everything lands under gpurun_out/<tag>/ ; tools/collect_profiles.py <tag> then copies the summaries into profiles/.
+#   bench_1gpu.json      default bench.py run (live PMC, CPU baseline, accuracy) + pmc_hbm.json (the counters as a summary)
+#   kt/                  rocprofv3 --kernel-trace --stats of the same command (no PMC in that run, CPU leg skipped)
+#   configs.jsonl        every BASELINE configuration on one GPU (tools/run_configs.py)
+#   mutation_sweep.jsonl tools/mutation_sweep.py
+#   pmc_tor/ pmc_x64/    detailed SQ / TCP counter passes (one group per pass, never with a trace domain)
+#   phase_*.log          per-phase shader-clock shares from the diagnostic build (libpt_phase.so)
 set -eo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out
-mkdir -p "$O"
+O=$R/gpurun_out/$TAG
+rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-python3 "$R/bench.py" > "$O/bench_1gpu.json" 2> "$O/bench_1gpu.err"
+python3 "$R/bench.py" --steps 10 --warmup 2 --save-pmc "$O/pmc_hbm.json" > "$O/bench_1gpu.json" 2> "$O/bench_1gpu.err"
 echo "bench done"
-rm -rf "$O"/prof_kt "$O"/prof_fetch "$O"/prof_write "$O"/prof_sq1 "$O"/prof_sq2 "$O"/prof_sq3
-rocprofv3 --kernel-trace --stats -d "$O/prof_kt" -o kt --output-format csv -- python3 "$R/bench.py" --cpu-seconds 0 > "$O/prof_kt.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$O/kt" -o kt --output-format csv -- python3 "$R/bench.py" --cpu-seconds 0 --pmc off --no-configs3 > "$O/kt.log" 2>&1
 echo "kernel trace done"
-B="python3 $R/bench.py --cpu-seconds 0 --steps 1 --warmup 0"
-rocprofv3 --pmc FETCH_SIZE -d "$O/prof_fetch" -o p --output-format csv -- $B > "$O/prof_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$O/prof_write" -o p --output-format csv -- $B > "$O/prof_write.log" 2>&1
-echo "hbm passes done"
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS -d "$O/prof_sq1" -o p --output-format csv -- $B > "$O/prof_sq1.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU -d "$O/prof_sq2" -o p --output-format csv -- $B > "$O/prof_sq2.log" 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$O/prof_sq3" -o p --output-format csv -- $B > "$O/prof_sq3.log" 2>&1
-echo "sq passes done"
-CH=$(python3 -c "import json,sys; print(json.load(open('$O/bench_1gpu.json'))['roofline']['hbm']['chunks_per_tile'])")
-cd "$R" && python3 tools/summarize_pmc.py --tag "$TAG" --kernel-trace "$O/prof_kt" --pmc "$O/prof_fetch" "$O/prof_write" "$O/prof_sq1" "$O/prof_sq2" "$O/prof_sq3" --chunks "$CH" --out-dir "$O/profiles"
-cp "$O/bench_1gpu.json" "$O/profiles/${TAG}_bench_1gpu.json"
-tail -c 600 "$O/bench_1gpu.json"
+python3 "$R/tools/run_configs.py" > "$O/configs.jsonl" 2> "$O/configs.err"
+echo "configs done"
+python3 "$R/tools/mutation_sweep.py" > "$O/mutation_sweep.jsonl" 2> "$O/mutation.err"
+echo "mutation sweep done"
+GROUPS_=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"
+         "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVES"
+         "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU"
+         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum")
+i=0
+for g in "${GROUPS_[@]}"; do
+  i=$((i+1))
+  rocprofv3 --pmc $g -d "$O/pmc_tor/p$i" -o p --output-format csv -- python3 "$R/bench.py" --pmc-child --spp 256 --steps 1 --warmup 1 > "$O/pmc_tor_p$i.log" 2>&1
+  rocprofv3 --pmc $g -d "$O/pmc_x64/p$i" -o p --output-format csv -- python3 "$R/tools/c5_probe.py" 64 > "$O/pmc_x64_p$i.log" 2>&1
+done
+echo "pmc detail done"
+PT_HIP_LIB=$R/path-tracing_amd/lib/libpt_phase.so python3 "$R/tools/tor_probe.py" > "$O/phase_tor.log" 2>&1
+PT_HIP_LIB=$R/path-tracing_amd/lib/libpt_phase.so python3 "$R/tools/c5_probe.py" 64,195 > "$O/phase_x64_x195.log" 2>&1
+echo "phase timers done"
+tail -c 400 "$O/bench_1gpu.json"
