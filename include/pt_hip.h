@@ -145,6 +145,7 @@ typedef struct pt_session pt_session;
 int pt_session_create(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end,
                       pt_session **out);                       /* accumulators start at zero */
 int pt_session_render(pt_session *session, const pt_render_params *params, pt_render_stats *stats);
+int pt_session_wait(pt_session *session);                                           /* until every slice queued so far is done */
 int pt_session_read(pt_session *session, float *sum, float *sum2, int32_t *count);   /* waits, then copies out */
 int pt_session_clear(pt_session *session);
 void pt_session_destroy(pt_session *session);
@@ -155,8 +156,9 @@ void pt_session_destroy(pt_session *session);
  * The culling hierarchy's float-error margins are derived for the rays the integrator itself produces: unit
  * directions (normalised as Ray's constructor does, ray.h:23) and origins with max |component| <= max(20, largest
  * |vertex coordinate|) + 1 (the camera at (0,0,-20), or a point on a surface).  A ray outside that envelope
- * (| |d|^2 - 1 | > 1e-5, a farther or a non-finite origin) is answered by the reference's own loop over ALL
- * triangles on the device instead, so every finite ray gets the reference's answer; only the speed differs.
+ * (| |d|^2 - 1 | > 1e-5, a farther origin) is answered by the reference's own loop over ALL triangles on the
+ * device instead, so every finite ray gets the reference's answer; only the speed differs.  A ray with a non-finite
+ * component misses (all its distances are NaN, see the deviation below).
  * eps < 0 is allowed and means what it means in the reference: the last test of Triangle::Intersect,
  * abs(..) > eps (triangles.h:68), then rejects every triangle, so every ray misses.
  * Known deviation: a ray lying EXACTLY in a triangle's stored plane makes PlaneIntersect (triangles.h:10-13) return
@@ -204,6 +206,12 @@ int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clu
  * scene, 64 bytes per node (path-tracing_amd/csrc/pt_scene.hpp: BvhNode).  Pass NULL to skip either.
  * In pt_scene_cull_tables the cluster fields first_tri / n_tri are slot ranges. */
 int pt_scene_cull_layout(pt_scene *scene, float eps, int32_t *counts, int32_t *slot_triangle, void *bvh_nodes);
+
+/* Page-locked host memory for accumulator buffers: transfers to and from it run at PCIe speed without the runtime's
+ * staging copies (a first pageable transfer in a fresh process cost 0.1 s for a 1080p band here).  Optional: every entry
+ * point also accepts ordinary (pageable) memory.  Returns NULL on failure; pt_host_free(NULL) is a no-op. */
+void *pt_host_alloc(size_t bytes);
+void pt_host_free(void *p);
 
 /* ---- misc ------------------------------------------------------------------------------------------- */
 int pt_abi_version(void);

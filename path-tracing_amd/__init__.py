@@ -29,10 +29,10 @@ TESTHOOKS_LIB_PATH = os.path.join(_HERE, "lib", "libpt_testhooks.so")
 # every symbol include/pt_hip.h declares
 ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_scene_get_triangles",
                "pt_scene_get_materials", "pt_scene_destroy", "pt_render_device", "pt_render_host", "pt_trace_rays_host",
-               "pt_session_create", "pt_session_render", "pt_session_read", "pt_session_clear", "pt_session_destroy",
+               "pt_session_create", "pt_session_render", "pt_session_wait", "pt_session_read", "pt_session_clear", "pt_session_destroy",
                "pt_scene_cull_tables", "pt_scene_cull_layout", "pt_scene_set_skybox_bmp", "pt_resolve", "pt_resolve_float",
                "pt_post_filter_host", "pt_quantize",
-               "pt_write_bmp", "pt_abi_version", "pt_device_count", "pt_last_error"]
+               "pt_write_bmp", "pt_host_alloc", "pt_host_free", "pt_abi_version", "pt_device_count", "pt_last_error"]
 
 
 class PtError(RuntimeError):
@@ -112,6 +112,7 @@ def load_library(path):
     L.pt_session_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.pt_session_render.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(RenderStats)]
     L.pt_session_read.argtypes = [vp, fp, fp, ip]
+    L.pt_session_wait.argtypes = [vp]
     L.pt_session_clear.argtypes = [vp]
     L.pt_session_destroy.argtypes = [vp]
     L.pt_session_destroy.restype = None
@@ -125,6 +126,10 @@ def load_library(path):
     L.pt_quantize.argtypes = [C.c_int32, C.c_int32, fp, ip, C.POINTER(C.c_uint8)]
     L.pt_write_bmp.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
     L.pt_last_error.restype = C.c_char_p
+    L.pt_host_alloc.restype = C.c_void_p
+    L.pt_host_alloc.argtypes = [C.c_size_t]
+    L.pt_host_free.argtypes = [C.c_void_p]
+    L.pt_host_free.restype = None
     if hasattr(L, "pt_test_set_mutation"):
         L.pt_test_set_mutation.argtypes = [C.c_char_p, C.c_double]
     return L

@@ -237,6 +237,19 @@ extern "C" {
 
 int pt_abi_version(void) { return PT_ABI_VERSION; }
 
+void *pt_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        g_error = "pt_host_alloc: hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void pt_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int pt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -829,6 +842,15 @@ int pt_session_create(pt_scene *scene, int32_t width, int32_t height, int32_t ro
 
 int pt_session_render(pt_session *session, const pt_render_params *params, pt_render_stats *stats) {
     return guarded([&] { return session_render_impl(session, params, stats); });
+}
+
+int pt_session_wait(pt_session *session) {
+    return guarded([&] {
+        if (!session) return fail(PT_ERR_INVALID_ARGUMENT, "null session");
+        PT_HIP_TRY(hipSetDevice(session->scene->device));
+        PT_HIP_TRY(hipStreamSynchronize(session->stream));
+        return static_cast<int>(PT_OK);
+    });
 }
 
 int pt_session_read(pt_session *session, float *sum, float *sum2, int32_t *count) {

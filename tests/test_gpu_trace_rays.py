@@ -140,3 +140,59 @@ def test_root_round_and_its_fallbacks(tmp_path, n_tri, n_rays):
     gi, gt = g.trace_rays(org2, -dirs)
     ri, rt, _ = o.closest_hits(org2, -dirs)
     assert np.array_equal(gi, ri) and np.array_equal(gt.view(np.uint32), rt.view(np.uint32)) and (ri == n_tri - 1).all()
+
+
+def test_rays_outside_the_envelope_get_the_reference_answer(models_dir, oracle_scene, tmp_path):
+    """pt_trace_rays_host accepts any ray.  The culling margins are derived for unit directions and origins within
+    r_org = max(20, largest |coordinate|) + 1; rays outside that envelope -- far origins (|o| up to 1e5, where the
+    sphere test's |m|^2 - (m.d)^2 would cancel catastrophically), unnormalised directions, non-finite origins -- are
+    answered by the reference's all-triangles loop on the device, so the answer is still the reference's, bit for bit.
+    Both the small-scene kernel (Tor.obj) and the box-tree kernel (a replicated scene)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_replicated_scene as M
+    d_ = str(tmp_path) + "/"
+    M.generate(os.path.join(root, "models"), d_, "x9.obj", 9)
+    rng = np.random.default_rng(12)
+    for g, o_scene in ((pt.Scene.load_obj(models_dir, "Tor.obj", device=0), oracle_scene),
+                       (pt.Scene.load_obj(d_, "x9.obj", device=0), O.Scene.load(d_, "x9.obj"))):
+        n = 6000
+        tgt = rng.uniform(-8, 8, (n, 3))
+        far = rng.normal(size=(n, 3))
+        far = far / np.linalg.norm(far, axis=1, keepdims=True) * rng.choice([25.0, 1e3, 1e4, 1e5], n)[:, None]
+        o = far.astype(np.float32)
+        d = _normalise((tgt - far).astype(np.float32))
+        # a third of them with directions that are NOT unit length (scaled by 0.5 ... 3): t scales by the inverse
+        scale = np.where(np.arange(n) % 3 == 0, rng.uniform(0.5, 3.0, n), 1.0).astype(np.float32)
+        d = (d * scale[:, None]).astype(np.float32)
+        # and inside origins mixed in, so that one wave holds both kinds
+        inside = np.arange(n) % 4 == 1
+        o[inside] = rng.uniform(-9, 9, (inside.sum(), 3)).astype(np.float32)
+        hits = _check(g, o_scene, o, d)
+        assert (hits >= 0).mean() > 0.3
+    g = pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+    o = np.array([[np.inf, 0, 0], [np.nan, 0, 0], [0, 0, -20]], np.float32)
+    d = np.array([[0, 0, 1], [0, 0, 1], [0, 0, 1]], np.float32)
+    gi, gt = g.trace_rays(o, d)
+    ri, rt, _ = oracle_scene.closest_hits(o, d)
+    assert np.array_equal(gi[2:], ri[2:]) and gi[2] >= 0            # the finite ray is answered
+    # non-finite origins make every distance NaN: the reference then "accepts" by failing every comparison (the known NaN
+    # deviation of pt_hip.h); here such rays simply miss -- and must not crash or disturb the other lanes of their wave
+    assert gi[0] == -1 and gi[1] == -1
+
+
+def test_negative_eps_means_every_ray_misses(models_dir, oracle_scene):
+    """eps < 0: the last test of Triangle::Intersect, abs(..) > eps (triangles.h:68), rejects every triangle -- in the
+    reference and here alike, for explicit rays and for frames."""
+    g = pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+    tri, _ = oracle_scene.triangles()
+    o, d = _adversarial_rays(tri, np.random.default_rng(9), 4000)
+    gi, gt = g.trace_rays(o, d, eps=-1e-4)
+    ri, rt, nan_seen = oracle_scene.closest_hits(o, d, -1e-4)
+    ok = ~nan_seen
+    assert (gi[ok] == -1).all() and (ri[ok] == -1).all() and np.isinf(gt[ok]).all()
+    s, s2, c, st = g.render_host(32, 24, 4, 8, eps=-1e-4)
+    rs, rs2, rc, rst = O.render(oracle_scene, 32, 24, 4, 8, eps=-1e-4)
+    assert st["segments"] == rst["segments"] == st["misses"] == 32 * 24 * 4 and not c.any() and not rc.any()

@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
-"""Copies what tools/profile_round.sh, profile_c3.sh, run_configs.py and pmc_passes.sh left under gpurun_out/ into
-profiles/ (the tracked summaries) and prints the numbers the documents quote.
+"""Copies what tools/profile_round.sh left under gpurun_out/<tag>/ into profiles/ (the tracked summaries) and prints the
+numbers the documents quote.
 
-    python tools/collect_profiles.py [--tag r01]
+    python tools/collect_profiles.py [--tag r02]
+
+    profiles/<tag>_bench_1gpu.json        the default bench.py line
+    profiles/<tag>_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command
+    profiles/<tag>_pmc_hbm.json           the live counters bench.py collected (kernel_source_sha, kernel_ms): --pmc file reads it
+    profiles/<tag>_pmc_detail.json        SQ / TCP counter passes of the timed Tor.obj kernel and of the x64 replica, with derived ratios
+    profiles/<tag>_configs_one_gpu.jsonl  every BASELINE configuration on one GPU
+    profiles/<tag>_mutation_sweep.jsonl   tools/mutation_sweep.py
+    profiles/<tag>_phase_shares.txt       per-phase shader-clock shares (libpt_phase.so)
 """
 import argparse
 import collections
@@ -11,79 +19,89 @@ import glob
 import json
 import os
 import shutil
-import subprocess
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+P = os.path.join(ROOT, "profiles")
 
 
-def detail(name, timed_only):
-    d = collections.defaultdict(list)
-    for f in sorted(glob.glob(os.path.join(G, name, "p*", "p_counter_collection.csv"))):
+def detail(d, timed_only):
+    m = collections.defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(d, "p*", "p_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "integrate" in k and (not timed_only or k.replace(" ", "").endswith("false>(pt::RenderArgs)")):
-                d[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    if not d:
+                m[r["Counter_Name"]].append((r["Dispatch_Id"], float(r["Counter_Value"])))
+    if not m:
         return None
-    m = {k: sum(v) / len(v) for k, v in d.items()}
-    cyc = m["GRBM_GUI_ACTIVE"] / 8
-    m["derived"] = {"shader_cycles": cyc, "valu_issue_utilisation": m["SQ_INSTS_VALU"] * 2 / (cyc * 1024),
-                    "tcp_accesses_per_cu_over_cycles": m["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / cyc,
-                    "l1_hit_rate": 1 - m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"],
-                    "wave_cycles_waiting_on_waitcnt": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
-                    "wave_cycles_waiting_for_issue": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]}
-    return m
+    out = {}
+    for k, v in m.items():
+        per = collections.defaultdict(float)
+        for disp, val in v:
+            per[disp] += val
+        out[k] = sum(per.values()) / len(per)
+    cyc = out["GRBM_GUI_ACTIVE"] / 8
+    out["derived"] = {"shader_cycles": cyc, "valu_issue_utilisation": out["SQ_INSTS_VALU"] * 2 / (cyc * 1024),
+                      "valu_active_lane_fraction": out["SQ_THREAD_CYCLES_VALU"] / (out["SQ_INSTS_VALU"] * 64),
+                      "tcp_accesses_per_cu_over_cycles": out["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / cyc,
+                      "l1_hit_rate": 1 - out["TCP_TCC_READ_REQ_sum"] / out["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                      "wave_cycles_waiting_on_waitcnt": out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"],
+                      "wave_cycles_waiting_for_issue": out["SQ_WAIT_INST_ANY"] / out["SQ_WAVE_CYCLES"],
+                      "valu_instructions_per_wave": out["SQ_INSTS_VALU"] / out["SQ_WAVES"]}
+    return out
+
+
+def phase_shares(path, names):
+    lines = []
+    for l in open(path):
+        if l.startswith("PT_PHASE_TIMERS cycles:"):
+            c = [int(x) for x in l.split(":")[1].split()]
+            tot = sum(c)
+            lines.append("  " + ", ".join(f"{n} {100 * v / tot:.1f} %" for n, v in zip(names, c) if v))
+        elif "amdgpu.ids" not in l and l.strip():
+            lines.append(l.rstrip())
+    return lines
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r01")
+    ap.add_argument("--tag", default="r02")
     a = ap.parse_args()
     t = a.tag
-    chunks = json.load(open(os.path.join(G, "bench_1gpu.json")))["roofline"]["hbm"]["chunks_per_tile"]
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), "--tag", t, "--kernel-trace",
-                           os.path.join(G, "prof_kt"), "--pmc"] + [os.path.join(G, f"prof_{k}") for k in ("fetch", "write", "sq1", "sq2", "sq3")] +
-                          ["--chunks", str(chunks)], stdout=subprocess.DEVNULL)
+    G = os.path.join(ROOT, "gpurun_out", t)
+    os.makedirs(P, exist_ok=True)
     shutil.copy(os.path.join(G, "bench_1gpu.json"), os.path.join(P, f"{t}_bench_1gpu.json"))
-    if os.path.exists(os.path.join(G, "bench_c3.json")):
-        c3 = json.load(open(os.path.join(G, "bench_c3.json")))
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), "--tag", f"{t}_c3", "--spp", "1024",
-                               "--kernel-trace", os.path.join(G, "c3_kt"), "--pmc"] + [os.path.join(G, f"c3_{k}") for k in ("fetch", "write", "sq")] +
-                              ["--chunks", str(c3["roofline"]["hbm"]["chunks_per_tile"])], stdout=subprocess.DEVNULL)
-        shutil.copy(os.path.join(G, "bench_c3.json"), os.path.join(P, f"{t}_bench_c3_1024spp.json"))
-    if os.path.exists(os.path.join(G, "configs.jsonl")):
-        shutil.copy(os.path.join(G, "configs.jsonl"), os.path.join(P, f"{t}_configs_one_gpu.jsonl"))
+    shutil.copy(os.path.join(G, "pmc_hbm.json"), os.path.join(P, f"{t}_pmc_hbm.json"))
+    shutil.copy(os.path.join(G, "configs.jsonl"), os.path.join(P, f"{t}_configs_one_gpu.jsonl"))
+    shutil.copy(os.path.join(G, "mutation_sweep.jsonl"), os.path.join(P, f"{t}_mutation_sweep.jsonl"))
+    ks = max(glob.glob(os.path.join(G, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    shutil.copy(ks, os.path.join(P, f"{t}_kernel_stats.csv"))
     out = {}
-    for name, label, timed in (("torpmc", "Tor.obj 1920x1080x64spp (bench.py, timed kernel integrate_kernel<false,false,false>)", True),
-                               ("c5pmc", "replicated scene x64, 16398 triangles, 1920x1080x8spp (tools/c5_probe.py, integrate_kernel<false,true,true>)", False)):
-        m = detail(name, timed)
+    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (bench.py --pmc-child, timed kernel integrate_kernel<false,false,false>)", True),
+                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x8spp (tools/c5_probe.py, integrate_kernel<false,true,true>)", False)):
+        m = detail(os.path.join(G, name), timed)
         if m:
             out[label] = m
     json.dump(out, open(os.path.join(P, f"{t}_pmc_detail.json"), "w"), indent=1)
+    names = ["ray generation / loop control", "cluster + top-level tests", "tree walk (box-tree rounds)", "barycentric cull of the large class",
+             "pair publication", "exact rounds (final drains)", "pre-filter + exact inside the box walk", "shading"]
+    txt = ["# Per-phase shares of the waves' shader-clock cycles (diagnostic build libpt_phase.so, -DPT_PHASE_TIMERS: s_memtime stamps).",
+           "# Tor.obj 1920x1080x16spp (tools/tor_probe.py):"] + phase_shares(os.path.join(G, "phase_tor.log"), names) + \
+          ["# replicated scenes x64 and x195, 1920x1080x8spp (tools/c5_probe.py):"] + phase_shares(os.path.join(G, "phase_x64_x195.log"), names)
+    open(os.path.join(P, f"{t}_phase_shares.txt"), "w").write("\n".join(txt) + "\n")
     b = json.load(open(os.path.join(P, f"{t}_bench_1gpu.json")))
-    h = json.load(open(os.path.join(P, f"{t}_pmc_hbm.json")))
-    c = h["counters_per_launch"]
-    print(f"bench: {b['value']:.0f} Msamples/s, kernel {b['roofline']['kernel_ms']:.2f} ms, frac {b['roofline']['frac']:.2f} "
-          f"({b['roofline']['achieved']:.0f} TFLOP/s-eq), pcie {b['pcie_inclusive']['value']:.0f} ({b['pcie_inclusive']['ms_per_step']:.1f} ms), "
-          f"e2e {b['end_to_end']['seconds']:.2f} s, cpu {b.get('cpu_baseline', {}).get('value')}")
-    print(f"pmc: VALU util {h['valu_issue_utilisation']:.3f}, HBM {h['hbm_bytes_per_launch'] / 1e6:.0f} MB "
-          f"(fetch {c['FETCH_SIZE'] * 1024 / 1e6:.0f}, write {c['WRITE_SIZE'] * 1024 / 1e6:.0f}), VALU instr {c['SQ_INSTS_VALU']:.3g}")
+    rf = b["roofline"]
+    print(f"bench: {b['value']:.0f} Msamples/s, {b['ms_per_step']:.2f} ms/step, kernel {rf['kernel_ms']:.2f} ms, frac {rf['frac']:.3f} "
+          f"({rf['achieved']:.1f} Tlane-op/s), lanes active {rf['valu_active_lane_fraction']:.3f}, traffic {rf['traffic'] / 1e6:.0f} MB "
+          f"({rf['hbm']['traffic_over_algorithmic']:.2f}x), ref-eq {rf['reference_equivalent_tflops']:.0f} TFLOP/s")
+    print(f"  configs3 {b['configs3_strong']['value']:.0f}, pcie {b['pcie_inclusive']['value']:.0f} ({b['pcie_inclusive']['ms_per_step']:.1f} ms), "
+          f"e2e {b['end_to_end']['seconds']:.2f} s {b['end_to_end']['phases']}, cpu {b['cpu_baseline']['value']:.2f} / {b['cpu_baseline']['value_4_threads']:.2f}")
     for k, v in out.items():
-        print(k[:48], {kk: round(vv, 3) for kk, vv in v["derived"].items()})
-    for f in (f"{t}_kernel_stats.csv", f"{t}_c3_kernel_stats.csv"):
-        if os.path.exists(os.path.join(P, f)):
-            print(open(os.path.join(P, f)).read().splitlines()[1][:140])
-    if os.path.exists(os.path.join(P, f"{t}_bench_c3_1024spp.json")):
-        c3 = json.load(open(os.path.join(P, f"{t}_bench_c3_1024spp.json")))
-        h3 = json.load(open(os.path.join(P, f"{t}_c3_pmc_hbm.json")))
-        print(f"c3: {c3['value']:.0f} Msamples/s, kernel {c3['roofline']['kernel_ms']:.1f} ms, e2e {c3['end_to_end']['seconds']:.2f} s, "
-              f"VALU util {h3['valu_issue_utilisation']:.3f}, HBM {h3['hbm_bytes_per_launch'] / 1e6:.0f} MB")
-    if os.path.exists(os.path.join(P, f"{t}_configs_one_gpu.jsonl")):
-        for line in open(os.path.join(P, f"{t}_configs_one_gpu.jsonl")):
-            j = json.loads(line)
-            print(j["config"], j["kernel_ms"], j.get("kernel_ms_with_statistics"), j["nominal_Msamples_per_s"], j["traced_Msamples_per_s"])
+        print(k[:40], {kk: round(vv, 3) for kk, vv in v["derived"].items()})
+    print(open(os.path.join(P, f"{t}_kernel_stats.csv")).read()[:600])
+    for line in open(os.path.join(P, f"{t}_configs_one_gpu.jsonl")):
+        j = json.loads(line)
+        print(j["config"], j["triangles"], j["kernel_ms"], j["nominal_Msamples_per_s"], j["traced_Msamples_per_s"], j["node_rounds_per_wave_segment"])
+    print("\n".join(txt))
 
 
 if __name__ == "__main__":
