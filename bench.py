@@ -37,6 +37,7 @@ import hashlib
 import importlib
 import json
 import os
+import re
 import shutil
 import socket
 import subprocess
@@ -67,6 +68,12 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def timed_instantiation(kernel_name):
+    """integrate_kernel<SKY, BIG, STATS, ENV>: the timed launches are the statistics-free ones (third argument false)."""
+    m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)>", kernel_name.replace(" ", ""))
+    return bool(m) and m.group(3) == "false"
 
 
 def kernel_source_sha():
@@ -132,7 +139,7 @@ def pmc_live(args, timeout_s=240):
                 return None, f"rocprofv3 pass {group} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
             rows = [x for x in csv.DictReader(open(max(files, key=os.path.getmtime))) if "integrate_kernel" in x["Kernel_Name"]]
             # the timed launches run the instantiation without statistics (third template argument false)
-            rows = [x for x in rows if x["Kernel_Name"].replace(" ", "").endswith("false>(pt::RenderArgs)")]
+            rows = [x for x in rows if timed_instantiation(x["Kernel_Name"])]
             launches = len({x["Dispatch_Id"] for x in rows})
             if not launches:
                 return None, f"no integrate_kernel dispatch in pass {group}"
@@ -402,7 +409,7 @@ def main():
                 # strided accumulator loads, calibrated 0.76-1.0 : 1 on their known byte count
                 traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         if args.save_pmc and pmc and pmc_source.startswith("rocprofv3"):
-            json.dump({"kernel": "pt::integrate_kernel<false,false,false>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
+            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
                        "kernel_source_sha": kernel_source_sha(), "kernel_ms": kms, "counters_per_launch": pmc,
                        "collected_by": "bench.py --save-pmc: " + pmc_source,
                        "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes; SQ_INSTS_VALU counts wave-instructions"},
@@ -426,7 +433,7 @@ def main():
             "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": achieved / PEAK_VALU_TLANEOPS if achieved is not None else None,
                          "traffic": traffic,
-                         "kernel": "pt::integrate_kernel<false,false,false>", "kernel_ms": kms,
+                         "kernel": "pt::integrate_kernel<false,false,false,false>", "kernel_ms": kms,
                          "what": "achieved = executed VALU lane-operations (SQ_INSTS_VALU x 64) / live HIP-event kernel time; "
                                  "peak = 1024 SIMDs x 32 lanes x 2.4 GHz (no FMA: parity forbids contraction)",
                          "counters_source": pmc_source, "kernel_source_sha": kernel_source_sha(),

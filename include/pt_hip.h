@@ -164,7 +164,9 @@ void pt_session_destroy(pt_session *session);
  * Known deviation: a ray lying EXACTLY in a triangle's stored plane makes PlaneIntersect (triangles.h:10-13) return
  * 0/0 = NaN, which passes every comparison of Triangle::Intersect -- the reference then reports that triangle wherever
  * it is.  No geometric cull can follow that; for such a ray this function returns the closest regular hit instead.
- * The integrator cannot produce such rays (DESIGN.md "Known deviation"). */
+ * The integrator cannot produce such rays (DESIGN.md "Known deviation").  The same holds for a triangle whose stored
+ * plane is itself NaN (three collinear vertices and no `vn`: normalize(0)): the reference reports it for every ray,
+ * this library never does. */
 int pt_trace_rays_host(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps,
                        int32_t *hit_index, float *hit_t);
 

@@ -196,9 +196,11 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.sky_h = scene->sky_h;
     a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
     a.n_tri = scene->host.n_tri();
+    a.n_slots = static_cast<uint32_t>(scene->cull.host.slot_tri.size());
     a.eps = eps;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.m0_quad = cc.m0_quad; a.t_guard = cc.t_guard;
     a.r_org = scene->cull.host.r_org;
+    a.may_leave_envelope = scene->cull.host.may_leave_envelope ? 1 : 0;
 }
 
 // No exception may cross the C boundary: allocation failures and anything else become status codes.
@@ -469,6 +471,15 @@ static int render_device_impl(pt_scene *scene, const pt_render_params *p, float 
         stats->partial_commit_rounds = static_cast<int32_t>(std::min<unsigned long long>(h[8], 0x7fffffffull));
         stats->verify_checked = h[9];      // both stay 0 unless this is the verification build (-DPT_VERIFY_BRUTE)
         stats->verify_mismatches = h[10];
+#ifdef PT_TEST_HOOKS
+        if (h[10] != 0) {   // verification build: one disagreeing segment, for diagnosis
+            auto f = [](unsigned long long w, int hi) { const uint32_t b = static_cast<uint32_t>(hi ? w >> 32 : w); float x; std::memcpy(&x, &b, 4); return x; };
+            std::fprintf(stderr, "PT_VERIFY example: all-triangles loop -> triangle %d (key %016llx), culled search -> triangle %d (key %016llx); "
+                                 "ray o = (%.9g, %.9g, %.9g) d = (%.9g, %.9g, %.9g)\n",
+                         static_cast<int>(h[11] & 0xFFFFFFFFu), h[11], static_cast<int>(h[12] & 0xFFFFFFFFu), h[12],
+                         f(h[13], 1), f(h[13], 0), f(h[14], 1), f(h[14], 0), f(h[15], 1), f(h[15], 0));
+        }
+#endif
 #ifdef PT_PHASE_TIMERS
         std::fprintf(stderr, "PT_PHASE_TIMERS cycles:");
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[16 + k]);

@@ -306,7 +306,7 @@ struct WaveLds {
     unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
     float ray[6][64];              // this segment's rays, readable by every lane
     uint32_t nodes[kNodeStack + 64];// LIFO of tree nodes to expand: lane << 26 | level << 23 | node index within its level
-    uint32_t pairs[kPairQueue];    // (ray, triangle) work items: slot index | lane << 24
+    uint32_t pairs[kPairQueue];    // (ray, triangle) work items: slot index | lane << 24 | kUnfiltered << 24
     uint32_t level_off[kMaxLevels];// sphere offset of each level of the cluster being walked
     uint32_t level_cnt[kMaxLevels];// number of real nodes of each level
     float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
@@ -349,6 +349,8 @@ struct NoStats {
 #else
 #define PT_STAMP(st, idx) do { } while (0)
 #endif
+
+constexpr uint32_t kUnfiltered = 64u;   // added to the lane number of a pair: the pre-filter must not judge it
 
 // float -> uint32 whose unsigned order is the float order (for ds_min_u64 keys)
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
@@ -418,9 +420,8 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
 
 // Scene::TraceRay's triangle loop exactly as the reference runs it (scene.cpp:116-120): every triangle, in index order,
 // through Triangle::Intersect for this lane's ray; returns the closest-hit key (~0 = miss).  Wave-uniform control flow.
-// Used for rays outside the envelope the culling margins were derived for (pt_trace_rays_host) and by the verification
-// build; the integrator's shipped instantiations never call it.
-__device__ __noinline__ unsigned long long brute_force_key(const RenderArgs &a, const Ray &q, float eps) {
+// Only the verification build calls it.
+__device__ __forceinline__ unsigned long long brute_force_key(const RenderArgs &a, const Ray &q, float eps) {
     unsigned long long best = ~0ull;
     for (int i = 0; i < a.n_tri; ++i) {
         uint32_t orig;
@@ -433,9 +434,12 @@ __device__ __noinline__ unsigned long long brute_force_key(const RenderArgs &a, 
     return best;
 }
 
-template <class Lds, class Stats>
-__device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray &q, bool valid, int lane,
+template <bool ENV, class Lds, class Stats>
+__device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray &q, bool live, bool in_envelope, int lane,
                                             float eps, float &best, int &hit, const ExactRec *&hit_rec, Stats &st) {
+    // `valid` below = rays that go through the culling hierarchy; live rays outside the envelope its margins were derived
+    // for get every slot as a candidate instead (rare: see the caller).
+    const bool valid = live && in_envelope;
     constexpr uint32_t kNodeStack = Lds::kNodeStack, kPairQueue = Lds::kPairQueue;
     // Small scenes (at most kBigSceneTriangles = 2048 triangles, so 16 bits each): the closest-hit key carries the SLOT
     // below the original index, and shading reads the slot-ordered record the exact test has just pulled through the
@@ -459,7 +463,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         ++st.w_exact_iters;
         st.n_exact += cnt;
         if (active) {
-            const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
+            const uint32_t src = (e >> 24) & 63u, tri = e & 0xFFFFFFu;
             Ray r;
             r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
             r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
@@ -483,7 +487,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 // test, and the survivors are re-packed so that exact rounds stay full.
                 bool keep = false;
                 if (active) {
-                    const uint32_t src = e >> 24, tri = e & 0xFFFFFFu;
+                    const uint32_t src = (e >> 24) & 63u, tri = e & 0xFFFFFFu;
                     Ray r;
                     r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                     r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
@@ -493,7 +497,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     rec.n[0] = c0.x; rec.n[1] = c0.y; rec.n[2] = c0.z; rec.w = c0.w;
                     rec.au[0] = c1.x; rec.au[1] = c1.y; rec.au[2] = c1.z; rec.cu = c1.w;
                     rec.av[0] = c2.x; rec.av[1] = c2.y; rec.av[2] = c2.z; rec.cv = c2.w;
-                    keep = !cull_reject(rec, r, a.k1, a.k2, a.a_max_all, a.m0_all, a.t_guard_all);
+                    keep = !cull_reject(rec, r, a.k1, a.k2, a.a_max_all, a.m0_all, a.t_guard_all) || (e >> 30) != 0u;   // bit 30: never filtered
+#ifdef PT_DBG_NO_PREFILTER
+                    keep = true;
+#endif
                 }
                 const unsigned long long ball = __ballot(keep);
                 if (keep) lds.filtered[n_filtered + lanes_below(ball)] = e;
@@ -568,6 +575,17 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             pend_open = true;
         }
     };
+
+    // ---- 0. rays outside the envelope: all slots are candidates (padding slots carry NaN planes and are never accepted);
+    // their pairs carry bit 30 = "skip the barycentric pre-filter", whose margins assume the envelope as well
+    if constexpr (ENV) if (__builtin_expect(__any(live && !in_envelope), 0)) {
+        const bool far = live && !in_envelope;
+        for (uint32_t base = 0; base < a.n_slots; base += 32u) {
+            const uint32_t left = a.n_slots - base;
+            const uint32_t all = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+            push_pairs_any(far ? all : 0u, base, static_cast<uint32_t>(lane) | kUnfiltered);
+        }
+    }
 
     // ---- 1. cull
     const ConstF clusters = (ConstF)reinterpret_cast<uintptr_t>(a.clusters);
@@ -845,7 +863,11 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                     r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
                     const uint32_t bh = static_cast<uint32_t>(lds.best[src] >> 32);
+#ifdef PT_DBG_NO_PRUNE
+                    const float t_best = bh == 0x12345u ? 0.0f : __builtin_inff();
+#else
                     const float t_best = bh == 0xFFFFFFFFu ? __builtin_inff() : from_ordered_bits(bh);
+#endif
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     m8 = box_children_kept(q0, q1, q2, q3, r, t_best, a.bvh_err);
@@ -922,9 +944,16 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     // triangle through Triangle::Intersect for this lane's own ray -- and a comparison of the two closest hits.
     {
         const unsigned long long brute = brute_force_key(a, q, eps);
-        st.v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid)));
+        st.v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(live)));
         const unsigned long long mine = (key == ~0ull) ? ~0ull : ((key & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(hit));
-        st.v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid && brute != mine)));
+        st.v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(live && brute != mine)));
+        if (live && brute != mine && a.stats) {   // one example for the host to print (any of them)
+            a.stats[11] = brute;
+            a.stats[12] = mine;
+            a.stats[13] = (static_cast<unsigned long long>(__float_as_uint(q.ox)) << 32) | __float_as_uint(q.oy);
+            a.stats[14] = (static_cast<unsigned long long>(__float_as_uint(q.oz)) << 32) | __float_as_uint(q.dx);
+            a.stats[15] = (static_cast<unsigned long long>(__float_as_uint(q.dy)) << 32) | __float_as_uint(q.dz);
+        }
     }
 #endif
     best = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
@@ -938,7 +967,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 // the register peak, and the no-skybox kernel (every BASELINE configuration) should not pay for it.
 // BIG = deep work queues for scenes with thousands of triangles (see SmallQueues / BigQueues).
 // STATS = the caller asked for pt_render_stats.
-template <bool SKY, bool BIG, bool STATS>
+// ENV = some triangle of the scene can be "hit" outside the envelope the culling margins are derived for (near-degenerate
+// triangles; CullTables::may_leave_envelope): every segment's origin is then checked.  A compile-time choice because the
+// mere presence of the rare path costs the common scenes 2 % (measured), whether or not it ever runs.
+template <bool SKY, bool BIG, bool STATS, bool ENV>
 __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;   // one wave per workgroup: all wave-private
 
@@ -1043,7 +1075,15 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
             float best;
             int hit;
             const ExactRec *hit_rec;
-            closest_hit(a, lds, q, valid, lane, eps, best, hit, hit_rec, wst);
+            // The culling margins hold for origins within r_org of the scene (pt_scene.cpp).  A path can leave that envelope:
+            // the reference accepts a near-degenerate triangle for points that have nothing to do with it, at any distance
+            // (all three computed sub-areas can vanish), and the next segment then starts millions of units away.  For such
+            // a ray nothing is culled: every triangle goes through the exact test.  (A NaN origin counts as outside.)
+            // (one v_max3_f32 with |.| modifiers and one compare; an origin here is never NaN: it is o + d t + N eps of finite terms)
+            bool inside = true;
+            if constexpr (ENV)
+                inside = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.ox), __builtin_fabsf(q.oy)), __builtin_fabsf(q.oz)) <= a.r_org;
+            closest_hit<ENV>(a, lds, q, valid, inside, lane, eps, best, hit, hit_rec, wst);
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
             if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
@@ -1236,8 +1276,8 @@ __global__ __launch_bounds__(kBlock, BIG ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_
         q.ox = origins[3 * i]; q.oy = origins[3 * i + 1]; q.oz = origins[3 * i + 2];
         q.dx = directions[3 * i]; q.dy = directions[3 * i + 1]; q.dz = directions[3 * i + 2];
     }
-    // Rays outside the envelope the culling margins were derived for (pt_hip.h: pt_trace_rays_host) take the reference's
-    // loop over all triangles instead; written so that NaNs count as outside.
+    // Rays outside the envelope the culling margins were derived for (pt_hip.h: pt_trace_rays_host) get every triangle as
+    // a candidate for the exact test instead; written so that NaNs count as outside.
     const float d2 = (q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz;
     const bool inside = __builtin_fabsf(q.ox) <= a.r_org && __builtin_fabsf(q.oy) <= a.r_org && __builtin_fabsf(q.oz) <= a.r_org &&
                         __builtin_fabsf(d2 - 1.0f) <= 1.0e-5f;
@@ -1245,14 +1285,7 @@ __global__ __launch_bounds__(kBlock, BIG ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_
     int hit;
     const ExactRec *hit_rec;
     WaveStats st;
-    closest_hit(a, lds, q, valid && inside, lane, a.eps, best, hit, hit_rec, st);
-    if (__any(valid && !inside)) {
-        const unsigned long long key = brute_force_key(a, q, a.eps);
-        if (!inside) {
-            hit = (key == ~0ull) ? -1 : static_cast<int>(key & 0xFFFFFFFFu);
-            best = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
-        }
-    }
+    closest_hit<true>(a, lds, q, valid, inside, lane, a.eps, best, hit, hit_rec, st);
     if (valid) {
         hit_index[i] = hit;
         hit_t[i] = best;
@@ -1281,16 +1314,23 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     const bool stats = args.stats != nullptr;
 #endif
     auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args); };
+    auto pick = [&](auto sky, auto bg, auto st) {
+        constexpr bool S = decltype(sky)::value, B = decltype(bg)::value, T = decltype(st)::value;
+        if (args.may_leave_envelope) go(integrate_kernel<S, B, T, true>);
+        else go(integrate_kernel<S, B, T, false>);
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
     if (stats) {
-        if (args.sky && big) go(integrate_kernel<true, true, true>);
-        else if (args.sky) go(integrate_kernel<true, false, true>);
-        else if (big) go(integrate_kernel<false, true, true>);
-        else go(integrate_kernel<false, false, true>);
+        if (args.sky && big) pick(Yes(), Yes(), Yes());
+        else if (args.sky) pick(Yes(), No(), Yes());
+        else if (big) pick(No(), Yes(), Yes());
+        else pick(No(), No(), Yes());
     } else {
-        if (args.sky && big) go(integrate_kernel<true, true, false>);
-        else if (args.sky) go(integrate_kernel<true, false, false>);
-        else if (big) go(integrate_kernel<false, true, false>);
-        else go(integrate_kernel<false, false, false>);
+        if (args.sky && big) pick(Yes(), Yes(), No());
+        else if (args.sky) pick(Yes(), No(), No());
+        else if (big) pick(No(), Yes(), No());
+        else pick(No(), No(), No());
     }
     return hipGetLastError();
 }

@@ -28,6 +28,7 @@ struct RenderArgs {
     int32_t *count;
     unsigned long long *stats;   // 24 counters (11 used; 16.. = phase timers of diagnostic builds) or nullptr
     int32_t n_clusters, n_tri;
+    uint32_t n_slots;            // slots of the hierarchy (>= n_tri: the box tree pads its leaves)
     int32_t width, height, row_begin, row_end;
     int32_t pass_begin, pass_count, mrr;
     float eps, error;
@@ -39,6 +40,7 @@ struct RenderArgs {
     int32_t chunk_passes;               // passes per chunk
     int32_t vec_ok;                     // sum / sum2 / count are 16-byte aligned and width % 4 == 0: 16-byte write-back allowed
     float r_org;                        // origins with a component beyond this are outside the cull margins' envelope
+    int32_t may_leave_envelope;         // 0: no triangle of this scene can be hit outside the envelope, the integrator skips the test
 };
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);

@@ -801,6 +801,17 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         groups.erase(std::remove_if(groups.begin(), groups.end(), [](const std::vector<int> &g) { return g.empty(); }), groups.end());
     }
     const bool big = T > kBigSceneTriangles;
+    // Can a path leave the envelope (origins within r_org) the margins are derived for?  Only through a hit point outside
+    // it, i.e. only if some triangle's acceptance region reaches beyond it: a near-degenerate triangle (the reference
+    // accepts it for points anywhere along its axis) or a long sliver at the edge of the scene.  Scenes without such
+    // triangles (Tor.obj, the replicas) skip the per-segment origin test altogether.
+    out.may_leave_envelope = false;
+    for (int i = 0; i < T && !out.may_leave_envelope; ++i) {
+        if (geo[i].degenerate) { out.may_leave_envelope = true; break; }
+        const Box b = acceptance_box(geo[i], eps_line);
+        for (int x = 0; x < 3; ++x)
+            if (!(b.lo[x] > -(r_org - 0.01)) || !(b.hi[x] < r_org - 0.01)) out.may_leave_envelope = true;
+    }
 
     // ---- slot order of the small class
     std::vector<int> order;                       // slot -> triangle (-1 = padding)

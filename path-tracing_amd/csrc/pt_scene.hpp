@@ -124,6 +124,7 @@ struct CullTables {
     CullConstants cc;
     float eps = 0;
     float r_org = 0;                 // the margins hold for ray origins with every |component| <= r_org
+    bool may_leave_envelope = false; // some triangle can be "hit" at a point outside that envelope (near-degenerate triangles)
 };
 
 #ifdef PT_TEST_HOOKS

@@ -18,10 +18,17 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+
+
+def timed_instantiation(kernel_name):
+    """integrate_kernel<SKY, BIG, STATS, ENV>: the timed launches are the statistics-free ones (third argument false)."""
+    m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)>", kernel_name.replace(" ", ""))
+    return bool(m) and m.group(3) == "false"
 
 
 def detail(d, timed_only):
@@ -29,7 +36,7 @@ def detail(d, timed_only):
     for f in sorted(glob.glob(os.path.join(d, "p*", "p_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "integrate" in k and (not timed_only or k.replace(" ", "").endswith("false>(pt::RenderArgs)")):
+            if "integrate" in k and (not timed_only or timed_instantiation(k)):
                 m[r["Counter_Name"]].append((r["Dispatch_Id"], float(r["Counter_Value"])))
     if not m:
         return None
@@ -76,8 +83,8 @@ def main():
     ks = max(glob.glob(os.path.join(G, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(ks, os.path.join(P, f"{t}_kernel_stats.csv"))
     out = {}
-    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (bench.py --pmc-child, timed kernel integrate_kernel<false,false,false>)", True),
-                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x8spp (tools/c5_probe.py, integrate_kernel<false,true,true>)", False)):
+    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (bench.py --pmc-child, timed kernel integrate_kernel<false,false,false,false>)", True),
+                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x8spp (tools/c5_probe.py, integrate_kernel<false,true,true,false>)", False)):
         m = detail(os.path.join(G, name), timed)
         if m:
             out[label] = m
