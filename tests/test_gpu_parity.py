@@ -247,3 +247,59 @@ def test_device_pointer_path_on_two_streams(gpu_scene):
         h = b.cpu().numpy()
         assert _same(h[:3 * n], s.ravel()) and _same(h[3 * n:6 * n], s2.ravel())
         assert np.array_equal(h[6 * n:].view(np.int32), c)
+
+
+def test_sessions_keep_the_band_on_the_device(gpu_scene, oracle_scene):
+    """pt_session_*: pass slices added to device-resident accumulators equal one pt_render_host call (and the oracle) bit
+    for bit; a session can be read at any point, cleared and reused; mismatching parameters are refused."""
+    W, H, mrr = 72, 40, 8
+    s, s2, c, _ = gpu_scene.render_host(W, H, 30, mrr, error=0.001)
+    ses = pt.Session(gpu_scene, W, H)
+    for p0, n in [(0, 4), (4, 11), (15, 15)]:
+        ses.render(p0, n, mrr, error=0.001)
+    a, a2, ac = ses.read()
+    assert _same(a, s) and _same(a2, s2) and np.array_equal(ac, c)
+    rs, rs2, rc, _ = O.render(oracle_scene, W, H, 30, mrr, error=0.001)
+    assert _same(a, rs) and np.array_equal(ac, rc)
+    b, b2, bc = ses.read()                                   # reading does not disturb the accumulators
+    assert _same(b, s) and np.array_equal(bc, c)
+    st = ses.render(30, 2, mrr, error=0.001, want_stats=True)   # statistics of one slice
+    assert st["samples_traced"] <= W * H * 2 and st["segments"] > 0
+    ses.clear()
+    z, z2, zc = ses.read()
+    assert not z.any() and not z2.any() and not zc.any()
+    ses.render(0, 30, mrr, error=0.001)
+    a, a2, ac = ses.read()
+    assert _same(a, s) and np.array_equal(ac, c)
+    # a row band of a larger image
+    band = pt.Session(gpu_scene, W, H, rows=(8, 24))
+    band.render(0, 30, mrr, error=0.001)
+    d, d2, dc = band.read()
+    assert _same(d, s[8 * W:24 * W]) and np.array_equal(dc, c[8 * W:24 * W])
+    # parameters that describe another band are refused
+    p = pt.RenderParams(W, H + 1, 0, H + 1, 0, 1, mrr, 1e-4, -1.0, 42, 0)
+    assert pt.lib().pt_session_render(ses._h, __import__("ctypes").byref(p), None) == 1
+    assert b"band" in pt.lib().pt_last_error()
+    ses.close(); band.close()
+
+
+def test_pinned_host_buffers_through_the_abi(gpu_scene):
+    """pt_host_alloc: page-locked accumulators passed to pt_render_host give the same frame as pageable ones."""
+    import ctypes as C
+    W, H, spp, mrr = 64, 48, 6, 8
+    s, s2, c, _ = gpu_scene.render_host(W, H, spp, mrr)
+    n = W * H
+    L = pt.lib()
+    ptrs = [L.pt_host_alloc(12 * n), L.pt_host_alloc(12 * n), L.pt_host_alloc(4 * n)]
+    assert all(ptrs)
+    try:
+        arrs = [np.ctypeslib.as_array(C.cast(ptrs[0], C.POINTER(C.c_float)), (n, 3)), np.ctypeslib.as_array(C.cast(ptrs[1], C.POINTER(C.c_float)), (n, 3)),
+                np.ctypeslib.as_array(C.cast(ptrs[2], C.POINTER(C.c_int32)), (n,))]
+        for a in arrs:
+            a[...] = 0
+        gpu_scene.render_host(W, H, spp, mrr, accum=tuple(arrs), want_stats=False)
+        assert _same(arrs[0], s) and _same(arrs[1], s2) and np.array_equal(arrs[2], c)
+    finally:
+        for p in ptrs:
+            L.pt_host_free(p)
+    L.pt_host_free(None)
