@@ -118,3 +118,7 @@ def test_random_scene(tmp_path, seed, n_small, n_large, n_dup):
     rs, rs2, rc, rst = O.render(o, W, H, spp, 8)
     assert st["segments"] == rst["segments"] and np.array_equal(c, rc)
     assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)) and np.array_equal(s2.view(np.uint32), rs2.view(np.uint32))
+    # the statistics-free instantiation of the same kernel (these scenes have near-degenerate slivers, so it is the variant
+    # with the envelope test compiled in: integrate_kernel<.., .., false, true>)
+    q = g.render_host(W, H, spp, 8, want_stats=False)
+    assert np.array_equal(q[2], rc) and np.array_equal(q[0].view(np.uint32), rs.view(np.uint32))
