@@ -62,7 +62,7 @@ def build(force=False):
     """Compile libpt_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-C", CSRC_DIR, "clean", "-s"])
-    subprocess.check_call(["make", "-C", CSRC_DIR, "-s"])
+    subprocess.check_call(["make", "-C", CSRC_DIR, "-s", "-j4"])   # the product library + the test / diagnostic builds
     return LIB_PATH
 
 
