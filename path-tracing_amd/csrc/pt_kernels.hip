@@ -2,23 +2,25 @@
 // all passes x segments x triangles of a row band in one launch.
 //
 // Per path segment a wave does three things:
-//   1. CULL   the triangles of a cluster (a run of small triangles) hang under an 8-ary tree of bounding spheres.  The
-//             top of the tree is tested wave-uniformly (records through scalar loads, used straight from SGPRs); below
-//             it the wave keeps a LIFO of (ray, node) work items in LDS and deals them out evenly, lane l expanding the
-//             l-th item whoever's ray it is.  Large triangles (walls) get a barycentric test instead of spheres.
-//             Every test is CONSERVATIVE with respect to the reference's Triangle::Intersect (triangles.h:48-73): it
-//             may only say "cannot be a hit".  Survivors become (ray, triangle) pairs in a second LDS queue.
+//   1. CULL   triangles are listed in SLOT order (pt_scene.hpp): the table builder groups them spatially, whatever order the
+//             OBJ lists them in.  Large triangles (walls) get a barycentric test, wave-uniformly, records through scalar
+//             loads and used straight from SGPRs.  Small triangles hang under a hierarchy: in scenes of up to 2048 triangles
+//             an 8-ary tree of bounding spheres per connected group, in bigger ones ONE tree of quantised boxes (64-byte
+//             nodes) over all of them.  Either tree is walked with a wave-wide LIFO of (ray, node) work items in LDS, dealt out
+//             evenly: lane l expands the l-th item whoever's ray it is.  The box walk also drops nodes entered beyond the
+//             ray's best hit so far.  Every test is CONSERVATIVE with respect to the reference's Triangle::Intersect
+//             (triangles.h:48-73): it may only say "cannot be a hit".  Survivors become (ray, slot) pairs in a second LDS queue.
 //   2. EXACT  the pairs (about 1.5 per ray) are dealt out evenly as well; each runs the reference's arithmetic operation
 //             for operation (same association, no FMA contraction, IEEE divide and sqrt), and the closest hit per ray is
-//             taken with one LDS atomic-min on (distance, index), so `t`, the hit decision and the closest-hit choice
-//             are bit-identical to the CPU path.
+//             taken with one LDS atomic-min on (distance, original triangle index), so `t`, the hit decision and the
+//             closest-hit choice are bit-identical to the CPU path.
 //   3. SHADE  Material::Process + the three lobes (material.h:36-102), Ray::Reflect (ray.h:45-50), the tile's accumulators
 //             (material.h:74-77) in LDS, counter-based Philox4x32-10 randoms keyed by (seed | pixel, pass, segment).
 //
 // Everything that decides a result is plain IEEE binary32/binary64 arithmetic (float sqrt and reciprocal through
 // pt_fastfp.hpp: shorter sequences, verified against the correctly rounded result for every float of their range); only
 // step 1 uses fused multiply-adds and raw v_rcp_f32 results, and step 1 cannot change a result (DESIGN.md "Culling: why it
-// cannot reject a hit").
+// cannot reject a hit"; the verification build, -DPT_VERIFY_BRUTE, re-checks every segment against the all-triangles loop).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
