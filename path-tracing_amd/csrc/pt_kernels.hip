@@ -1305,6 +1305,66 @@ hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, con
     return hipGetLastError();
 }
 
+#ifdef PT_BLOCK_PROFILE
+// the instantiations the instrumented code object must contain (nothing in this build references them)
+#define PT_INST(S, B) \
+    template __global__ void integrate_kernel<S, B, false, false>(const RenderArgs); \
+    template __global__ void integrate_kernel<S, B, true, false>(const RenderArgs);  \
+    template __global__ void integrate_kernel<S, B, false, true>(const RenderArgs);  \
+    template __global__ void integrate_kernel<S, B, true, true>(const RenderArgs);
+PT_INST(false, false) PT_INST(false, true) PT_INST(true, false) PT_INST(true, true)
+#undef PT_INST
+}  // namespace pt
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+namespace pt {
+// Diagnostic build (libpt_blockprof.so): the integrator is launched from an INSTRUMENTED copy of this file's code object
+// (tools/asm_profile.py inserts an execution counter in front of every straight-line run of instructions of the compiler's
+// own assembly) and the counters are written to $PT_BLOCKPROF_OUT.<kernel> after every launch.  Never part of the product.
+hipError_t launch_integrator(const RenderArgs &args0, hipStream_t stream) {
+    constexpr size_t kCounters = 4096;
+    static hipModule_t mod = nullptr;
+    static uint32_t *d_cnt = nullptr;
+    const int rows = args0.row_end - args0.row_begin;
+    if (rows <= 0 || args0.width <= 0) return hipSuccess;
+    if (!mod) {
+        const char *path = std::getenv("PT_BLOCKPROF_HSACO");
+        if (!path) return hipErrorInvalidValue;
+        hipError_t e = hipModuleLoad(&mod, path);
+        if (e != hipSuccess) return e;
+        e = hipMalloc(reinterpret_cast<void **>(&d_cnt), kCounters * sizeof(uint32_t));
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipMemsetAsync(d_cnt, 0, kCounters * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    RenderArgs args = args0;
+    args.blockprof = d_cnt;
+    char name[128];
+    std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dEEEvNS_10RenderArgsE", args.sky ? 1 : 0,
+                  args.n_tri > kBigSceneTriangles ? 1 : 0, args.stats ? 1 : 0, args.may_leave_envelope ? 1 : 0);
+    hipFunction_t f;
+    e = hipModuleGetFunction(&f, mod, name);
+    if (e != hipSuccess) return e;
+    size_t size = sizeof args;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    e = hipModuleLaunchKernel(f, args.n_tiles * args.n_chunks, 1, 1, kBlock, 1, 1, 0, stream, nullptr, config);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    std::vector<uint32_t> h(kCounters);
+    e = hipMemcpy(h.data(), d_cnt, kCounters * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    if (const char *out = std::getenv("PT_BLOCKPROF_OUT")) {
+        if (FILE *fp = std::fopen((std::string(out) + "." + name + ".txt").c_str(), "w")) {
+            for (size_t i = 0; i < kCounters; ++i) if (h[i]) std::fprintf(fp, "%zu %u\n", i, h[i]);
+            std::fclose(fp);
+        }
+    }
+    return hipSuccess;
+}
+#else
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     const int rows = args.row_end - args.row_begin;
     if (rows <= 0 || args.width <= 0) return hipSuccess;
@@ -1336,5 +1396,6 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     }
     return hipGetLastError();
 }
+#endif
 
 }  // namespace pt

@@ -41,6 +41,9 @@ struct RenderArgs {
     int32_t vec_ok;                     // sum / sum2 / count are 16-byte aligned and width % 4 == 0: 16-byte write-back allowed
     float r_org;                        // origins with a component beyond this are outside the cull margins' envelope
     int32_t may_leave_envelope;         // 0: no triangle of this scene can be hit outside the envelope, the integrator skips the test
+#ifdef PT_BLOCK_PROFILE
+    uint32_t *blockprof;                // diagnostic build only (tools/asm_profile.py): execution counters of the instrumented code object
+#endif
 };
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);

@@ -61,10 +61,12 @@ def main():
                 torch.cuda.synchronize(dev)
                 ms.append(e0.elapsed_time(e1))
             ms.sort()
+            import hashlib
+            digest = hashlib.sha1(buf.cpu().numpy().tobytes()).hexdigest()[:12]   # equal digests = bit-identical frames
             ws = max(1, st["wave_segments"])
             print(f"{name}{'' if mode is None else ' order_mode=' + str(mode)} {sn}: {W * H * a.spp / ms[1] / 1e3:.1f} Msamples/s  kernel {ms[1]:.2f} ms  "
                   f"node rounds/wseg {st['wave_node_rounds'] / ws:.2f}  exact rounds/wseg {st['wave_exact_iterations'] / ws:.2f}  "
-                  f"exact/seg {st['exact_tests'] / max(1, st['segments']):.3f}  partial {st['partial_commit_rounds']}", flush=True)
+                  f"exact/seg {st['exact_tests'] / max(1, st['segments']):.3f}  partial {st['partial_commit_rounds']}  frame {digest}", flush=True)
             sc.close()
 
 

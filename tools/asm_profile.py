@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Dynamic instruction profile of the integrator kernels, by instrumenting the COMPILER'S OWN assembly.
+
+There is no thread-trace decoder and no PC sampling on this pool, and DESIGN.md section 7 shows the kernel's time is
+proportional to the number of instructions its waves issue -- so the profile that matters is "how often does each
+instruction run".  This tool produces exactly that:
+
+    instrument  takes the device assembly of pt_kernels.hip (hipcc -S --cuda-device-only -gline-tables-only
+                -DPT_BLOCK_PROFILE), and in front of every straight-line run of instructions of the chosen kernels (a run
+                starts at a label or after a branch) inserts four instructions that add 1 to a per-wave LDS counter;
+                the counters are flushed to RenderArgs::blockprof at s_endpgm.  It writes the instrumented assembly
+                and a map  run id -> instructions of the run with their source lines.
+    report      joins the counters a run of libpt_blockprof.so wrote ($PT_BLOCKPROF_OUT.<kernel>.txt) with that map:
+                executed instructions per source line / per region, per wave-segment.
+
+The inserted code uses registers the kernel does not (v110.. , s[100:101]) and saves / restores EXEC; it changes no
+flag the surrounding code reads (s_mov does not write SCC; VCC is untouched after the prologue).  Waits only get longer
+(an extra LDS operation in flight).  tools/blockprof.sh drives the whole thing.
+"""
+import argparse
+import collections
+import json
+import re
+import sys
+
+LDS_BASE = 8192          # counters live above everything the kernels allocate themselves (<= 7232 bytes)
+MAX_RUNS = 1024
+INSTR = re.compile(r"\s+((?:v|s|ds|global|buffer|flat|scratch)_\w+)(.*)")
+
+
+def instrument(args):
+    kernels = args.kernels.split(",")
+    out, maps = [], {}
+    cur_kernel, run_id, cur_loc, runs = None, 0, None, None
+    pending_counter = False
+    lines = open(args.asm).read().split("\n")
+    i = 0
+
+    def counter(k):
+        return [f"\ts_mov_b64 s[100:101], exec", f"\ts_mov_b64 exec, 1", f"\tds_add_u32 v110, v111 offset:{LDS_BASE + 4 * k}",
+                f"\ts_mov_b64 exec, s[100:101]"]
+
+    def new_run():
+        nonlocal run_id
+        if run_id >= MAX_RUNS:
+            raise SystemExit("too many runs")
+        out.extend(counter(run_id))
+        runs.append([])
+        run_id += 1
+
+    while i < len(lines):
+        line = lines[i]
+        i += 1
+        m = re.match(r"(_ZN2pt16integrate_kernel\w+):", line)
+        if m and m.group(1) in kernels:
+            cur_kernel, run_id, runs = m.group(1), 0, []
+            maps[cur_kernel] = runs
+            out.append(line)
+            # prologue: v110 = LDS address 0, v111 = 1, v112 = lane * 4, v[114:115] = blockprof + lane * 4; counters zeroed
+            out += ["\tv_mov_b32 v110, 0", "\tv_mov_b32 v111, 1", f"\ts_load_dwordx2 s[100:101], s[0:1], {args.kernarg_offset}",
+                    "\tv_lshlrev_b32 v112, 2, v0"]
+            for j in range(MAX_RUNS // 64):
+                out.append(f"\tds_write_b32 v112, v110 offset:{LDS_BASE + 256 * j}")
+            out += ["\ts_waitcnt lgkmcnt(0)", "\tv_mov_b32 v114, s100", "\tv_mov_b32 v115, s101",
+                    "\tv_add_co_u32 v114, vcc, v114, v112", "\tv_addc_co_u32 v115, vcc, 0, v115, vcc"]
+            new_run()
+            continue
+        if cur_kernel is None:
+            out.append(line)
+            continue
+        if line.startswith(".Lfunc_end"):
+            cur_kernel = None
+            out.append(line)
+            continue
+        m = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", line)
+        if m:
+            cur_loc = (int(m.group(1)), int(m.group(2)))
+            out.append(line)
+            continue
+        if re.match(r"\.LBB\d+_\d+:", line):
+            out.append(line)
+            new_run()
+            continue
+        m = INSTR.match(line)
+        if not m:
+            out.append(line)
+            continue
+        op = m.group(1)
+        if op == "s_endpgm":
+            out += ["\ts_mov_b64 exec, -1", "\ts_waitcnt vmcnt(0) lgkmcnt(0)"]
+            for j in range(MAX_RUNS // 64):
+                if j and j % 16 == 0:
+                    out += ["\tv_add_co_u32 v114, vcc, 0x1000, v114", "\tv_addc_co_u32 v115, vcc, 0, v115, vcc"]
+                out += [f"\tds_read_b32 v116, v112 offset:{LDS_BASE + 256 * j}", "\ts_waitcnt lgkmcnt(0)",
+                        f"\tglobal_atomic_add v[114:115], v116, off offset:{256 * (j % 16)}"]
+            out += ["\ts_waitcnt vmcnt(0)", line]
+            continue
+        runs[-1].append([op, cur_loc[0] if cur_loc else -1, cur_loc[1] if cur_loc else 0])
+        out.append(line)
+        if op.startswith("s_cbranch") or op == "s_branch":
+            new_run()
+    text = "\n".join(out)
+    # kernel descriptors: room for the extra registers and the counters' LDS
+    def patch(block):
+        name = re.search(r"\.amdhsa_kernel (\S+)", block.group(0)).group(1)
+        if name not in kernels:
+            return block.group(0)
+        b = block.group(0)
+        b = re.sub(r"\.amdhsa_group_segment_fixed_size \d+", f".amdhsa_group_segment_fixed_size {LDS_BASE + 4 * MAX_RUNS}", b)
+        b = re.sub(r"\.amdhsa_next_free_vgpr \d+", ".amdhsa_next_free_vgpr 120", b)
+        b = re.sub(r"\.amdhsa_accum_offset \d+", ".amdhsa_accum_offset 120", b)
+        b = re.sub(r"\.amdhsa_next_free_sgpr \d+", ".amdhsa_next_free_sgpr 102", b)
+        return b
+    text = re.sub(r"\.amdhsa_kernel .*?\.end_amdhsa_kernel", patch, text, flags=re.S)
+    # the metadata (YAML note) carries the same numbers; the loader trusts the descriptor, but keep them consistent
+    for k in kernels:
+        def meta(mm):
+            b = mm.group(0)
+            b = re.sub(r"\.group_segment_fixed_size: \d+", f".group_segment_fixed_size: {LDS_BASE + 4 * MAX_RUNS}", b)
+            b = re.sub(r"\.vgpr_count:\s+\d+", ".vgpr_count:     120", b)
+            b = re.sub(r"\.sgpr_count:\s+\d+", ".sgpr_count:     108", b)
+            return b
+        text = re.sub(r"- \.agpr_count:.*?\.symbol:\s+" + re.escape(k) + r"\.kd", meta, text, flags=re.S)
+    open(args.out, "w").write(text)
+    files = {}
+    for mm in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', open(args.asm).read()):
+        files[int(mm.group(1))] = mm.group(3) or mm.group(2)
+    json.dump({"runs": maps, "files": files}, open(args.map, "w"))
+    for k, r in maps.items():
+        print(f"{k}: {len(r)} runs, {sum(len(x) for x in r)} instructions", file=sys.stderr)
+
+
+def kind(op):
+    if op in ("s_nop",):
+        return "nop"
+    if op == "s_waitcnt":
+        return "wait"
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith("s_cbranch") or op == "s_branch":
+        return "branch"
+    if op.startswith("s_load") or op.startswith("s_buffer"):
+        return "smem"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith("ds_"):
+        return "lds"
+    return "vmem"
+
+
+def report(args):
+    mp = json.load(open(args.map))
+    runs = mp["runs"][args.kernel]
+    files = {int(k): v for k, v in mp["files"].items()}
+    cnt = {}
+    for line in open(args.counters):
+        a, b = line.split()
+        cnt[int(a)] = int(b)
+    src = {}
+    per_line = collections.Counter()
+    per_kind = collections.Counter()
+    per_op = collections.Counter()
+    total = 0
+    for k, ins in enumerate(runs):
+        c = cnt.get(k, 0)
+        for op, f, l in ins:
+            per_line[(f, l)] += c
+            per_kind[kind(op)] += c
+            per_op[op] += c
+            total += c
+    ws = args.wave_segments or 1
+    print(f"kernel {args.kernel}: {total} instructions executed, {total / ws:.1f} per wave-segment ({ws} wave-segments)")
+    print("by kind (per wave-segment): " + "  ".join(f"{k} {v / ws:.1f}" for k, v in per_kind.most_common()))
+    print("top opcodes: " + "  ".join(f"{k} {v / ws:.1f}" for k, v in per_op.most_common(25)))
+    regions = []
+    if args.regions:
+        for r in open(args.regions):
+            r = r.strip()
+            if r and not r.startswith("#"):
+                f, a, b, name = r.split(None, 3)
+                regions.append((f, int(a), int(b), name))
+    per_region = collections.Counter()
+    unassigned = collections.Counter()
+    for (f, l), c in per_line.items():
+        fname = files.get(f, "?") if f >= 0 else "?"
+        for rf, a, b, name in regions:
+            if rf in fname and a <= l <= b:
+                per_region[name] += c
+                break
+        else:
+            unassigned[(fname, l)] += c
+    if regions:
+        print("\nby region (instructions per wave-segment, share):")
+        for name, c in per_region.most_common():
+            print(f"  {name:34s} {c / ws:8.1f}  {100.0 * c / total:5.1f} %")
+        rest = sum(unassigned.values())
+        print(f"  {'(not in any region)':34s} {rest / ws:8.1f}  {100.0 * rest / total:5.1f} %")
+    print("\nhottest source lines:")
+    for (f, l), c in per_line.most_common(args.top):
+        fname = files.get(f, "?") if f >= 0 else "?"
+        print(f"  {fname.split('/')[-1]}:{l:<5d} {c / ws:8.1f}  {100.0 * c / total:5.1f} %")
+    if args.runs_out:
+        with open(args.runs_out, "w") as fp:
+            for k, ins in enumerate(runs):
+                c = cnt.get(k, 0)
+                lines = collections.Counter((f, l) for _, f, l in ins)
+                top = " ".join(f"{l}x{n}" for (f, l), n in lines.most_common(5) if f == 0)
+                fp.write(f"{k:4d} exec/ws {c / ws:8.3f} n={len(ins):4d} instr/ws {c * len(ins) / ws:8.1f} | {top}\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    a = sub.add_parser("instrument")
+    a.add_argument("asm"); a.add_argument("out"); a.add_argument("map")
+    a.add_argument("--kernels", required=True)
+    a.add_argument("--kernarg-offset", type=int, required=True)
+    b = sub.add_parser("report")
+    b.add_argument("map"); b.add_argument("counters")
+    b.add_argument("--kernel", required=True)
+    b.add_argument("--wave-segments", type=float, default=0)
+    b.add_argument("--regions", default="")
+    b.add_argument("--top", type=int, default=40)
+    b.add_argument("--runs-out", default="")
+    args = ap.parse_args()
+    (instrument if args.cmd == "instrument" else report)(args)
+
+
+if __name__ == "__main__":
+    main()
