@@ -267,13 +267,29 @@ __device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, 
     return (stage_b && stage_c && stage_d) ? nd : -__builtin_inff();
 }
 
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
+// Inclusive prefix sum over the 64 lanes in six DPP additions: within rows of 16 lanes (row_shr 1, 2, 4, 8), then row 0
+// into row 1 and row 2 into row 3 (row_bcast:15), then rows 0-1 into rows 2-3 (row_bcast:31).  Lane 63 holds the total.
+// The work queues are filled with it: a lane's entries go to [base + exclusive prefix, ...), one ds_write per entry,
+// instead of one wave-wide ballot round per bit plane (which cost a fifth of the big-scene kernel's instructions,
+// profiles/r02_blockprof_*.txt) -- and the total, which the capacity checks need, comes for free.
+__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v) {
+    int x = static_cast<int>(v);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true);
+    return static_cast<uint32_t>(x);
+}
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63)); }
+// One LDS store per set bit of `bits`: entry = ebase + (bit index << shift), at queue[pos], queue[pos + 1], ...
+__device__ __forceinline__ void emit_bits(uint32_t *queue, uint32_t pos, uint32_t bits, uint32_t ebase, uint32_t shift = 0) {
+    while (bits != 0) {
+        const uint32_t j = __builtin_ctz(bits);
+        bits &= bits - 1;
+        queue[pos++] = ebase + (j << shift);
     }
-    return v;
 }
 // LDS traffic between lanes of ONE wave: the hardware executes a wave's LDS instructions in order, so only the
 // compiler has to be stopped from moving them across the hand-off.
@@ -519,41 +535,31 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             wave_sync();
         }
     };
-    // Append one pair per set bit of `bits` (bit j = triangle tri0 + j of ray `src`), compacting over the wave.
-    // The caller guarantees room for every bit (see `commit` below and the large-triangle branch).
-    auto push_pairs = [&](uint32_t bits, uint32_t tri0, uint32_t src) {
-        while (__any(bits != 0)) {
-            const bool has = bits != 0;
-            const unsigned long long ball = __ballot(has);
-            if (has) {
-                const uint32_t j = __builtin_ctz(bits);
-                bits &= bits - 1;
-                lds.pairs[n_pairs + lanes_below(ball)] = (tri0 + j) | (src << 24);
-            }
-            n_pairs += __builtin_popcountll(ball);
-        }
+    // Append one pair per set bit of `bits` (bit j = triangle tri0 + j of ray `src`): a prefix sum over the lanes' counts
+    // gives every lane its place in the queue (and the total).  `excl` / `total` come from wave_scan_inclusive of the
+    // lanes' popcounts; the caller guarantees room for `total` pairs.
+    auto emit_pairs = [&](uint32_t bits, uint32_t tri0, uint32_t src, uint32_t excl, uint32_t total) {
+        emit_bits(lds.pairs, n_pairs + excl, bits, tri0 | (src << 24));
+        n_pairs += total;
         wave_sync();
     };
-    // wave-wide sum of a small per-lane count (< 64): one ballot per bit instead of a shuffle tree
-    auto wave_sum = [&](uint32_t v, int bits) {
-        uint32_t total = 0;
-        for (int b = 0; b < bits; ++b) total += static_cast<uint32_t>(__builtin_popcountll(__ballot((v >> b) & 1u))) << b;
-        return total;
-    };
-    // push_pairs for masks of any width: makes room first, and slices the mask if one batch could exceed the queue
+    // for masks of any width: makes room first, and slices the mask if one batch could exceed the queue
     auto push_pairs_any = [&](uint32_t bits, uint32_t tri0, uint32_t src) {
-        const uint32_t total = wave_sum(__builtin_popcount(bits), 6);
+        const uint32_t cnt = __builtin_popcount(bits);
+        const uint32_t incl = wave_scan_inclusive(cnt), total = wave_last(incl);
         if (total == 0) return;
         if (n_pairs + total > kPairQueue) drain_pairs(0);
         if (total <= kPairQueue) {
-            push_pairs(bits, tri0, src);
+            emit_pairs(bits, tri0, src, incl - cnt, total);
             return;
         }
         for (uint32_t lo = 0; lo < 32u; lo += 2u) {   // <= 128 pairs per slice
             const uint32_t part = bits & (3u << lo);
             if (!__any(part != 0)) continue;
             if (n_pairs + 128u > kPairQueue) drain_pairs(0);
-            push_pairs(part, tri0, src);
+            const uint32_t pc2 = __builtin_popcount(part);
+            const uint32_t in2 = wave_scan_inclusive(pc2);
+            emit_pairs(part, tri0, src, in2 - pc2, wave_last(in2));
         }
     };
 
@@ -596,9 +602,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     constexpr int kDescWords = sizeof(ClusterDesc) / 4;
     for (int cl = 0; cl < a.n_clusters; ++cl) {
         const ConstF cp = clusters + kDescWords * cl;
-        const bool pc = valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q);
-        if (!__any(pc)) continue;
         const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
+        // (the large class is tested triangle by triangle anyway, and its bounding sphere is the scene's: nothing to gain from it)
+        const bool pc = kind == 0 ? valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q) : valid;
+        if (!__any(pc)) continue;
         if (kind == 0) {
             // ---- small triangles: an 8-ary tree of bounding spheres, walked with a wave-wide LIFO of (ray, node) items
             const uint32_t n_levels = ((ConstU)cp)[8];
@@ -653,25 +660,18 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                         else test(std::integral_constant<uint32_t, 8>());
                     }
                     wave_sync();   // every lane has read its ray's lane number before the stack is written
-                    const uint32_t tot = wave_sum(__builtin_popcount(m), 4);
+                    const uint32_t mc = __builtin_popcount(m);
+                    const uint32_t incl = wave_scan_inclusive(mc), tot = wave_last(incl);
                     if (clev == 0) {   // the level below the top is the triangles themselves
                         if (n_pairs + tot > kPairQueue) drain_pairs(0);
                         if (tot <= kPairQueue) {
-                            push_pairs(m, first_tri + c0, src);
+                            emit_pairs(m, first_tri + c0, src, incl - mc, tot);
                             rooted = true;
                         }
                     } else if (tot <= kNodeStack) {
-                        uint32_t nb = m;
-                        while (__any(nb != 0)) {
-                            const bool has = nb != 0;
-                            const unsigned long long ball = __ballot(has);
-                            if (has) {
-                                const uint32_t j = __builtin_ctz(nb);
-                                nb &= nb - 1;
-                                lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (clev << 23) | (c0 + j * cstep);
-                            }
-                            n_nodes += __builtin_popcountll(ball);
-                        }
+                        // bit j = node c0 + j * cstep of level clev (cstep = 1 << sh here)
+                        emit_bits(lds.nodes, n_nodes + incl - mc, m, (src << 26) | (clev << 23) | c0, sh);
+                        n_nodes += tot;
                         wave_sync();
                         rooted = true;
                     }
@@ -727,7 +727,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 const uint32_t cnt = min(64u, n_nodes);
                 // A round with few items spreads each item's 8 children over 2, 4 or 8 lanes (wave-uniform choice).
                 uint32_t shift = cnt <= 8u ? 3u : cnt <= 16u ? 2u : cnt <= 32u ? 1u : 0u;
-                uint32_t m8, src, level, child0, keep;
+                uint32_t m8, src, level, child0, keep, packed, incl, tot;
                 bool leaf;
                 for (;;) {
                     m8 = 0; src = 0; level = 1; child0 = 0;
@@ -759,43 +759,43 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                         m8 &= left >= 8u ? 0xFFu : ((1u << left) - 1u);
                     }
                     leaf = level == 1;   // children are triangles
-                    const uint32_t kids = __builtin_popcount(m8);
+                    uint32_t kids = __builtin_popcount(m8);
                     keep = cnt;          // items [0, keep) (from the top of the stack) are committed this round
-                    const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = wave_sum(leaf ? 0u : kids, 4);
-                    if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
-                    if (n_pairs + tot_tri <= kPairQueue && n_nodes - cnt + tot_node <= kNodeStack) break;
+                    // one prefix sum for both queues: tree nodes count in the low half of the word, triangles in the high half
+                    packed = leaf ? kids << 16 : kids;
+                    incl = wave_scan_inclusive(packed);
+                    tot = wave_last(incl);
+                    if (n_pairs + (tot >> 16) > kPairQueue) drain_pairs(0);
+                    if (n_pairs + (tot >> 16) <= kPairQueue && n_nodes - cnt + (tot & 0xFFFFu) <= kNodeStack) break;
                     if (shift != 0u) { shift = 0u; continue; }   // rare: redo the round one lane per item
                     // Rare: not everything fits.  Commit the longest prefix of lanes (= the top of the stack) whose
                     // children do; the other items stay where they are.  If not even the top item fits it is committed
                     // anyway: its (at most 8) children replace it, and since they are one level deeper the stack can
                     // outgrow kNodeStack by at most 7 per level, which is what the 64 slots of slack are for.
-                    const uint32_t it = wave_inclusive_scan(leaf ? kids : 0u, lane), in = wave_inclusive_scan(leaf ? 0u : kids, lane);
-                    const bool fits = static_cast<uint32_t>(lane) < cnt && n_pairs + it <= kPairQueue &&
-                                      (n_nodes - (lane + 1)) + in <= kNodeStack;
+                    const bool fits = static_cast<uint32_t>(lane) < cnt && n_pairs + (incl >> 16) <= kPairQueue &&
+                                      (n_nodes - (lane + 1)) + (incl & 0xFFFFu) <= kNodeStack;
                     const unsigned long long fb = __ballot(fits);
                     keep = (fb == ~0ull) ? 64u : static_cast<uint32_t>(__builtin_ctzll(~fb));
                     if (keep == 0) keep = 1;
                     ++st.w_partial;
                     if (static_cast<uint32_t>(lane) >= keep) m8 = 0;
+                    kids = __builtin_popcount(m8);
+                    packed = leaf ? kids << 16 : kids;
+                    incl = wave_scan_inclusive(packed);
+                    tot = wave_last(incl);
                     break;
                 }
                 n_nodes -= keep;
                 wave_sync();
-                // node children back on the stack
-                uint32_t nb = leaf ? 0u : m8;
-                while (__any(nb != 0)) {
-                    const bool has = nb != 0;
-                    const unsigned long long ball = __ballot(has);
-                    if (has) {
-                        const uint32_t c8 = __builtin_ctz(nb);
-                        nb &= nb - 1;
-                        lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | ((level - 1) << 23) | (child0 + c8);
-                    }
-                    n_nodes += __builtin_popcountll(ball);
+                // node children back on the stack, triangle children into the pair queue: one pass
+                {
+                    const uint32_t excl = incl - packed;
+                    emit_bits(leaf ? lds.pairs : lds.nodes, leaf ? n_pairs + (excl >> 16) : n_nodes + (excl & 0xFFFFu), m8,
+                              leaf ? ((first_tri + child0) | (src << 24)) : ((src << 26) | ((level - 1) << 23) | child0));
+                    n_nodes += tot & 0xFFFFu;
+                    n_pairs += tot >> 16;
                 }
                 wave_sync();
-                // triangle children become (ray, triangle) pairs
-                push_pairs(leaf ? m8 : 0u, first_tri + child0, src);
             }
             PT_STAMP(st, 2);   // balanced tree walk
         } else {
@@ -877,48 +877,44 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     leaf = node >= a.bvh_leaf0;
                     base = leaf ? (node - a.bvh_leaf0) * kFan : (q0.w >> 11);
                 }
-                const uint32_t kids = __builtin_popcount(m8);
+                uint32_t kids = __builtin_popcount(m8);
                 uint32_t keep = cnt;
-                // room for everything?  One sum of all children decides in the common case; the split into leaves' triangles and
-                // inner nodes' children is only worked out when that is not enough.
-                const uint32_t tot_all = wave_sum(kids, 4);
-                bool fits_all = n_pairs + tot_all <= kPairQueue && n_nodes - cnt + tot_all <= kNodeStack;
-                if (!fits_all) {
-                    const uint32_t tot_tri = wave_sum(leaf ? kids : 0u, 4), tot_node = tot_all - tot_tri;
-                    if (n_pairs + tot_tri > kPairQueue) drain_pairs(0);
-                    fits_all = n_pairs + tot_tri <= kPairQueue && n_nodes - cnt + tot_node <= kNodeStack;
-                }
-                if (!fits_all) {
+                // Children of inner nodes go back on the stack, triangles of leaves into the pair queue.  One prefix sum serves both
+                // (inner lanes count in the low half of the word, leaf lanes in the high half): its last lane says whether everything
+                // fits, its other lanes where each lane's entries go.
+                uint32_t packed = leaf ? kids << 16 : kids;
+                uint32_t incl = wave_scan_inclusive(packed);
+                uint32_t tot = wave_last(incl);
+                if (n_pairs + (tot >> 16) > kPairQueue) drain_pairs(0);
+                if (!(n_pairs + (tot >> 16) <= kPairQueue && n_nodes - cnt + (tot & 0xFFFFu) <= kNodeStack)) {
                     // Rare: not everything fits.  Commit the longest prefix of lanes (= the top of the stack) whose children do;
                     // the top item always commits (its children are one level deeper; the 64 slots of slack absorb them).
-                    const uint32_t it = wave_inclusive_scan(leaf ? kids : 0u, lane), in = wave_inclusive_scan(leaf ? 0u : kids, lane);
-                    const bool fits = static_cast<uint32_t>(lane) < cnt && n_pairs + it <= kPairQueue &&
-                                      (n_nodes - (lane + 1)) + in <= kNodeStack;
+                    const bool fits = static_cast<uint32_t>(lane) < cnt && n_pairs + (incl >> 16) <= kPairQueue &&
+                                      (n_nodes - (lane + 1)) + (incl & 0xFFFFu) <= kNodeStack;
                     const unsigned long long fb = __ballot(fits);
                     keep = (fb == ~0ull) ? 64u : static_cast<uint32_t>(__builtin_ctzll(~fb));
                     if (keep == 0) keep = 1;
                     ++st.w_partial;
                     if (static_cast<uint32_t>(lane) >= keep) m8 = 0;
+                    kids = __builtin_popcount(m8);
+                    packed = leaf ? kids << 16 : kids;
+                    incl = wave_scan_inclusive(packed);
+                    tot = wave_last(incl);
                 }
                 n_nodes -= keep;
-                wave_sync();
+                wave_sync();   // every lane has read its item before the stack is written
                 // (Measured and dropped: pushing the children of the far half of a node first, right-aligned over the push steps so
                 // that the next round is the near front of all rays.  Pruning is already within 10 % of what knowing the final hit
                 // from the start would give -- the walls are tested first and pairs as soon as 64 wait -- and the ordering's 25
                 // instructions per round cost as much as it saved.)
-                uint32_t nb = leaf ? 0u : m8;
-                while (__any(nb != 0)) {
-                    const bool has = nb != 0;
-                    const unsigned long long ball = __ballot(has);
-                    if (has) {
-                        const uint32_t c8 = __builtin_ctz(nb);
-                        nb &= nb - 1;
-                        lds.nodes[n_nodes + lanes_below(ball)] = (src << 26) | (base + c8);
-                    }
-                    n_nodes += __builtin_popcountll(ball);
+                {
+                    const uint32_t excl = incl - packed;
+                    emit_bits(leaf ? lds.pairs : lds.nodes, leaf ? n_pairs + (excl >> 16) : n_nodes + (excl & 0xFFFFu), m8,
+                              leaf ? (base | (src << 24)) : ((src << 26) | base));
+                    n_nodes += tot & 0xFFFFu;
+                    n_pairs += tot >> 16;
                 }
                 wave_sync();
-                push_pairs(leaf ? m8 : 0u, base, src);
                 PT_STAMP(st, 2);   // box-tree rounds
                 if (n_pairs >= 64u) drain_pairs(63);
                 PT_STAMP(st, 6);   // pre-filter + exact rounds inside the walk
@@ -1049,7 +1045,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
         int depth = mrr;
         if (!skip) {
             uint32_t w0, w1, w2, w3;
-            philox4x32_10(gpix, static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
+            philox4x32_10(opaque(gpix), static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
             const double jx = jitter_double(w0), jy = jitter_double(w1);
             // x, y are made opaque once per pass so that their int->double conversions (and the doubles of width and
             // height) are redone here instead of being hoisted out of the pass loop, where they would occupy eight
@@ -1135,7 +1131,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
                     const float4 m1v = reinterpret_cast<const float4 *>(a.mats + mi)[1];   // ks, chance1
                     const int4 m2v = reinterpret_cast<const int4 *>(a.mats + mi)[2];       // n_lobes, kind0, kind1
                     uint32_t w0, w1, w2, w3;
-                    philox4x32_10(gpix, static_cast<uint32_t>(pass), static_cast<uint32_t>(depth), 0u, a.seed, kPhiloxKey1,
+                    philox4x32_10(opaque(gpix), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth), 0u, a.seed, kPhiloxKey1,
                                   w0, w1, w2, w3);
                     int kind;
                     if (m2v.x == 0) {
