@@ -87,23 +87,35 @@ __device__ __forceinline__ double jitter_double(uint32_t w) {   // (-0.5,0.5)
 }
 
 // sin/cos of a float angle in [0, 2pi]: double +,-,* only, so the result is the same on every IEEE machine.
+// The sixteen double constants come from one table through the scalar cache (two s_load_dwordx16): as immediates each
+// costs two s_mov_b32, a third of this function's instructions.
+__constant__ double kSinCosTab[16] = {
+    0.63661977236758138, 1.57079632673412561417e+00, 6.07710050650619224932e-11, 0.5,
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06,
+    -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07,
+    2.08757232129817482790e-09, -1.13596475577881948265e-11};
 __device__ __forceinline__ void portable_sincos(float a, float &s_out, float &c_out) {
+    typedef const __attribute__((address_space(4))) double *ConstD;
+    ConstD t = (ConstD)reinterpret_cast<uintptr_t>(kSinCosTab);
+    asm volatile("" : "+s"(t));   // keeps the compiler from folding the table back into immediates
     const double x = static_cast<double>(a);
-    const int k = static_cast<int>(x * 0.63661977236758138 + 0.5);
+    const int k = static_cast<int>(x * t[0] + t[3]);
     const double kd = static_cast<double>(k);
-    const double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double r = (x - kd * t[1]) - kd * t[2];
     const double z = r * r;
-    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04
-                    + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double ps = t[4] + z * (t[5] + z * (t[6] + z * (t[7] + z * (t[8] + z * t[9]))));
     const double sn = r + r * (z * ps);
-    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
-                    + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
-    const double cs = (1.0 - 0.5 * z) + (z * z) * pc;
-    const int q = k & 3;
-    const double s = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
-    const double c = (q == 0) ? cs : (q == 1) ? -sn : (q == 2) ? -cs : sn;
-    s_out = static_cast<float>(s);
-    c_out = static_cast<float>(c);
+    const double pc = t[10] + z * (t[11] + z * (t[12] + z * (t[13] + z * (t[14] + z * t[15]))));
+    const double cs = (1.0 - t[3] * z) + (z * z) * pc;
+    // Quadrant k & 3 = 0: (sn, cs), 1: (cs, -sn), 2: (-sn, -cs), 3: (-cs, sn).  Rounding to float commutes with negation, so the
+    // pair is narrowed first and then swapped / sign-flipped with integer operations.
+    const uint32_t q = static_cast<uint32_t>(k);
+    const float sf = static_cast<float>(sn), cf = static_cast<float>(cs);
+    const bool odd = (q & 1u) != 0u;
+    const uint32_t ua = __float_as_uint(odd ? cf : sf), ub = __float_as_uint(odd ? sf : cf);
+    s_out = __uint_as_float(ua ^ ((q & 2u) << 30));
+    c_out = __uint_as_float(ub ^ (((q + 1u) & 2u) << 30));
 }
 
 // Portable atan / atan2 / acos for the skybox lookup (scene.cpp:127-128): double +,-,*,/,sqrt only, the same
@@ -810,7 +822,15 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
                 const uint32_t quads = w < kMaxLevels - 1 ? ((ConstU)cp)[9 + w] : 0u;   // bit k: slots k, k+1 are one quad record
                 uint32_t m = 0;
-                for (uint32_t k0 = 0; k0 < min(left, 32u); k0 += 2) {   // records are padded to whole words
+                const uint32_t cnt32 = min(left, 32u);
+                const uint32_t pair_bits = 0x55555555u & (cnt32 >= 32u ? 0xFFFFFFFFu : ((1u << cnt32) - 1u));
+                if (quads == pair_bits) {   // every record of the word is a quad (the walls of a room): no per-record dispatch
+                    for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {
+                        const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
+                        m |= (~rej & 3u) << k0;
+                    }
+                } else
+                for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {   // records are padded to whole words
                     if ((quads >> k0) & 1u) {   // wave-uniform
                         const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
                         m |= (~rej & 3u) << k0;
@@ -1159,29 +1179,31 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
                             contributed = true;
                         }
                         depth = mrr;
-                    } else if (kind == 1) {   // glossy, material.h:83-85
-                        const float dn = (pl.x * q.dx + pl.y * q.dy) + pl.z * q.dz;
-                        float rx = q.dx - pl.x * dn * 2.0f, ry = q.dy - pl.y * dn * 2.0f, rz = q.dz - pl.z * dn * 2.0f;
-                        normalize3(rx, ry, rz);
+                    } else {
+                        // Both scattering lobes end in Ray::Reflect (ray.h:45-50): the lobe-specific part leaves the new direction
+                        // (not yet normalised by Reflect) and the throughput factor, the common tail runs once per wave.
+                        float rx, ry, rz, fr, fg, fb;
+                        if (kind == 1) {   // glossy, material.h:83-85
+                            const float dn = (pl.x * q.dx + pl.y * q.dy) + pl.z * q.dz;
+                            rx = q.dx - pl.x * dn * 2.0f; ry = q.dy - pl.y * dn * 2.0f; rz = q.dz - pl.z * dn * 2.0f;
+                            fr = m1v.x; fg = m1v.y; fb = m1v.z;
+                        } else {   // diffuse, material.h:90-100
+                            const float xi1 = unit_float(w1), xi2 = unit_float(w2);
+                            const float ang = 2 * 3.141593f * xi2;
+                            float sn, cs;
+                            portable_sincos(ang, sn, cs);
+                            const float sq = sqrt_rn_normal(xi1);   // xi1 and 1 - xi1 are multiples of 2^-24 in [2^-24, 1)
+                            rx = sq * cs; ry = sq * sn; rz = sqrt_rn_normal(1 - xi1);
+                            normalize3(rx, ry, rz);
+                            if ((pl.x * rx + pl.y * ry) + pl.z * rz < 0) { rx *= -1; ry *= -1; rz *= -1; }
+                            float dt = (pl.x * rx + pl.y * ry) + pl.z * rz;
+                            dt = dt > 0.0f ? dt : 0.0f;
+                            fr = m0v.x * dt; fg = m0v.y * dt; fb = m0v.z * dt;
+                        }
+                        normalize3(rx, ry, rz);   // Ray::Reflect normalises (again), ray.h:47
                         q.ox = px + pl.x * eps; q.oy = py + pl.y * eps; q.oz = pz + pl.z * eps;
                         q.dx = rx; q.dy = ry; q.dz = rz;
-                        tr *= m1v.x; tg *= m1v.y; tb *= m1v.z;
-                        ++depth;
-                    } else {   // diffuse, material.h:90-100
-                        const float xi1 = unit_float(w1), xi2 = unit_float(w2);
-                        const float ang = 2 * 3.141593f * xi2;
-                        float sn, cs;
-                        portable_sincos(ang, sn, cs);
-                        const float sq = sqrt_rn_normal(xi1);   // xi1 and 1 - xi1 are multiples of 2^-24 in [2^-24, 1)
-                        float rx = sq * cs, ry = sq * sn, rz = sqrt_rn_normal(1 - xi1);
-                        normalize3(rx, ry, rz);
-                        if ((pl.x * rx + pl.y * ry) + pl.z * rz < 0) { rx *= -1; ry *= -1; rz *= -1; }
-                        float dt = (pl.x * rx + pl.y * ry) + pl.z * rz;
-                        dt = dt > 0.0f ? dt : 0.0f;
-                        normalize3(rx, ry, rz);   // Ray::Reflect normalises again, ray.h:47
-                        q.ox = px + pl.x * eps; q.oy = py + pl.y * eps; q.oz = pz + pl.z * eps;
-                        q.dx = rx; q.dy = ry; q.dz = rz;
-                        tr *= m0v.x * dt; tg *= m0v.y * dt; tb *= m0v.z * dt;
+                        tr *= fr; tg *= fg; tb *= fb;
                         ++depth;
                     }
                 }
