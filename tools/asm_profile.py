@@ -174,27 +174,46 @@ def report(args):
     print("top opcodes: " + "  ".join(f"{k} {v / ws:.1f}" for k, v in per_op.most_common(25)))
     regions = []
     if args.regions:
+        src_lines = open(args.source).read().split("\n")
+        at = 0
         for r in open(args.regions):
             r = r.strip()
-            if r and not r.startswith("#"):
-                f, a, b, name = r.split(None, 3)
-                regions.append((f, int(a), int(b), name))
+            if not r or r.startswith("#"):
+                continue
+            name, rx = [x.strip() for x in r.split("|", 1)]
+            for i in range(at, len(src_lines)):
+                if re.search(rx, src_lines[i]):
+                    regions.append([i + 1, len(src_lines) + 1, name])
+                    if len(regions) > 1:
+                        regions[-2][1] = i
+                    at = i + 1
+                    break
+            else:
+                raise SystemExit(f"region '{name}': no line after {at} matches {rx}")
     per_region = collections.Counter()
-    unassigned = collections.Counter()
+    other_files = collections.Counter()
+    main_name = args.source.split("/")[-1] if args.regions else ""
     for (f, l), c in per_line.items():
-        fname = files.get(f, "?") if f >= 0 else "?"
-        for rf, a, b, name in regions:
-            if rf in fname and a <= l <= b:
-                per_region[name] += c
-                break
+        fname = (files.get(f, "?") if f >= 0 else "?").split("/")[-1]
+        if regions and fname == main_name:
+            if l == 0:
+                per_region["(no source line: compiler-generated, inlined helpers without locations)"] += c
+                continue
+            for a, b, name in regions:
+                if a <= l <= b:
+                    per_region[name] += c
+                    break
+            else:
+                per_region["(before the first region)"] += c
         else:
-            unassigned[(fname, l)] += c
+            other_files[fname] += c
+    unassigned = other_files
     if regions:
         print("\nby region (instructions per wave-segment, share):")
         for name, c in per_region.most_common():
             print(f"  {name:34s} {c / ws:8.1f}  {100.0 * c / total:5.1f} %")
-        rest = sum(unassigned.values())
-        print(f"  {'(not in any region)':34s} {rest / ws:8.1f}  {100.0 * rest / total:5.1f} %")
+        for fname, c in other_files.most_common():
+            print(f"  {'[' + fname + ']':34s} {c / ws:8.1f}  {100.0 * c / total:5.1f} %")
     print("\nhottest source lines:")
     for (f, l), c in per_line.most_common(args.top):
         fname = files.get(f, "?") if f >= 0 else "?"
@@ -220,6 +239,7 @@ def main():
     b.add_argument("--kernel", required=True)
     b.add_argument("--wave-segments", type=float, default=0)
     b.add_argument("--regions", default="")
+    b.add_argument("--source", default="path-tracing_amd/csrc/pt_kernels.hip")
     b.add_argument("--top", type=int, default=40)
     b.add_argument("--runs-out", default="")
     args = ap.parse_args()
