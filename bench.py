@@ -116,7 +116,8 @@ def launch_ranks(args, argv):
 # touches the GPU.  One counter group per pass, never combined with a trace domain (MI355X_MICROARCH.md "rocprofv3 PMC
 # slots": FETCH_SIZE and WRITE_SIZE do not fit one pass).
 # ---------------------------------------------------------------------------------------------------------------------
-PMC_PASSES = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
+PMC_PASSES = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
+               "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
 
 
 def pmc_live(args, timeout_s=240):
@@ -415,6 +416,20 @@ def main():
                        "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes; SQ_INSTS_VALU counts wave-instructions"},
                       open(args.save_pmc, "w"), indent=1)
         achieved = lane_ops / (kms * 1e-3) / 1e12 if lane_ops and kms > 0 else None
+        # The second hardware view: the kernel's time follows the number of instructions its waves issue,
+        # vector or scalar alike (calibration builds with 200 extra instructions per wave-segment).  Issue slots = 2 cycles per
+        # wave64 vector instruction on a 32-lane SIMD + 1 per scalar / LDS / memory / branch instruction, against
+        # 1024 SIMDs x kernel time x 2.4 GHz.
+        issue = None
+        if pmc and all(k in pmc for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD")):
+            others = sum(pmc[k] for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD"))
+            wseg = float(frame_stats.get("wave_segments", 0)) or None
+            issue = {"instructions_per_launch": pmc["SQ_INSTS_VALU"] + others,
+                     "valu": pmc["SQ_INSTS_VALU"], "salu": pmc["SQ_INSTS_SALU"], "branch": pmc["SQ_INSTS_BRANCH"],
+                     "lds": pmc["SQ_INSTS_LDS"], "smem": pmc["SQ_INSTS_SMEM"], "vmem_rd": pmc["SQ_INSTS_VMEM_RD"],
+                     "instructions_per_wave_segment": (pmc["SQ_INSTS_VALU"] + others) / wseg if wseg else None,
+                     "issue_slot_fraction": (2.0 * pmc["SQ_INSTS_VALU"] + others) / (1024 * kms * 1e-3 * 2.4e9) if kms > 0 else None,
+                     "what": "(2 x vector + 1 x every other instruction) / (1024 SIMDs x kernel time x 2.4 GHz); s_nop / s_waitcnt not counted"}
         ref_eq = seg * n_tri * FLOP_PER_TEST / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out = {
             "metric": "Msamples/sec (WxHxspp/wall) on Tor.obj 1080p",
@@ -439,6 +454,7 @@ def main():
                          "counters_source": pmc_source, "kernel_source_sha": kernel_source_sha(),
                          "valu_instructions_per_launch": pmc.get("SQ_INSTS_VALU") if pmc else None,
                          "valu_active_lane_fraction": lane_frac,
+                         "issue": issue,
                          "segments_per_launch": seg, "exact_tests_per_segment": frame_stats["exact_tests"] / seg if seg else None,
                          "reference_equivalent_tflops": ref_eq, "reference_equivalent_over_fp32_peak": ref_eq / PEAK_FP32_VALU_TFLOPS,
                          "flop_per_test": FLOP_PER_TEST,

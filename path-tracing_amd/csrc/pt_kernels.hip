@@ -268,7 +268,7 @@ __device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, 
     const float q3 = area2_of(f2x, f2y, f2z, f1x, f1y, f1z);
     float s1, s2, s3;
     // one range check for the three roots: min and max of the squared areas decide for all of them
-    if (__all(fast_fp_ok(__builtin_fminf(__builtin_fminf(q1, q2), q3)) && fast_fp_ok(__builtin_fmaxf(__builtin_fmaxf(q1, q2), q3)))) {
+    if (__all(fast_fp_ok(__builtin_fminf(__builtin_fminf(q1, q2), q3)) & fast_fp_ok(__builtin_fmaxf(__builtin_fmaxf(q1, q2), q3)))) {
         s1 = sqrt_rn_normal(q1); s2 = sqrt_rn_normal(q2); s3 = sqrt_rn_normal(q3);
     } else {
         s1 = __builtin_sqrtf(q1); s2 = __builtin_sqrtf(q2); s3 = __builtin_sqrtf(q3);
@@ -884,7 +884,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     Ray r;
                     r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                     r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
-                    const uint32_t bh = static_cast<uint32_t>(lds.best[src] >> 32);
+                    const uint32_t bh = reinterpret_cast<const uint32_t *>(&lds.best[src])[1];   // high word: ordered bits of t
 #ifdef PT_DBG_NO_PRUNE
                     const float t_best = bh == 0x12345u ? 0.0f : __builtin_inff();
 #else

@@ -11,6 +11,7 @@ numbers the documents quote.
     profiles/<tag>_configs_one_gpu.jsonl  every BASELINE configuration on one GPU
     profiles/<tag>_mutation_sweep.jsonl   tools/mutation_sweep.py
     profiles/<tag>_phase_shares.txt       per-phase shader-clock shares (libpt_phase.so)
+    profiles/<tag>_blockprof_{tor,x64}.txt  executed instructions per source region / line (tools/asm_profile.py)
 """
 import argparse
 import collections
@@ -95,6 +96,26 @@ def main():
            "# Tor.obj 1920x1080x16spp (tools/tor_probe.py):"] + phase_shares(os.path.join(G, "phase_tor.log"), names) + \
           ["# replicated scenes x64 and x195, 1920x1080x8spp (tools/c5_probe.py):"] + phase_shares(os.path.join(G, "phase_x64_x195.log"), names)
     open(os.path.join(P, f"{t}_phase_shares.txt"), "w").write("\n".join(txt) + "\n")
+    # dynamic instruction profiles: counters of the instrumented code object joined with its map (tools/asm_profile.py)
+    import subprocess
+    import sys
+    mp = os.path.join(ROOT, "path-tracing_amd", "lib", "blockprof", "map.json")
+    for scene, kern in (("tor", "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0EEEvNS_10RenderArgsE"),
+                        ("x64", "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0EEEvNS_10RenderArgsE")):
+        cnt = os.path.join(G, f"blockprof_{scene}.{kern}.txt")
+        log = os.path.join(G, f"blockprof_{scene}.log")
+        if not (os.path.exists(cnt) and os.path.exists(mp) and os.path.exists(log)):
+            continue
+        ws = [l.split()[2] for l in open(log) if "wave_segments" in l][0]
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_profile.py"), "report", mp, cnt, "--kernel", kern,
+                            "--wave-segments", ws, "--regions", os.path.join(ROOT, "tools", "asm_profile_regions.txt"),
+                            "--source", os.path.join(ROOT, "path-tracing_amd", "csrc", "pt_kernels.hip"), "--top", "25"],
+                           capture_output=True, text=True, check=True)
+        head = (f"# Executed instructions of the timed integrator kernel, {'Tor.obj 1920x1080x8spp' if scene == 'tor' else 'x64 replica 1920x1080x4spp'}:\n"
+                "# tools/asm_profile.py instruments the compiler's own assembly (one counter per straight-line run), libpt_blockprof.so\n"
+                "# launches that code object; counts joined with the line tables.  The totals by kind agree with SQ_INSTS_VALU / SALU / BRANCH.\n")
+        open(os.path.join(P, f"{t}_blockprof_{scene}.txt"), "w").write(head + r.stdout)
+        print(r.stdout.split("\n")[0])
     b = json.load(open(os.path.join(P, f"{t}_bench_1gpu.json")))
     rf = b["roofline"]
     print(f"bench: {b['value']:.0f} Msamples/s, {b['ms_per_step']:.2f} ms/step, kernel {rf['kernel_ms']:.2f} ms, frac {rf['frac']:.3f} "

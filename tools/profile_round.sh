@@ -7,6 +7,7 @@
 #   mutation_sweep.jsonl tools/mutation_sweep.py
 #   pmc_tor/ pmc_x64/    detailed SQ / TCP counter passes (one group per pass, never with a trace domain)
 #   phase_*.log          per-phase shader-clock shares from the diagnostic build (libpt_phase.so)
+#   blockprof_*          execution counters of the instrumented code object (libpt_blockprof.so + lib/blockprof/pt_bp.hsaco)
 set -eo pipefail
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -35,4 +36,8 @@ echo "pmc detail done"
 PT_HIP_LIB=$R/path-tracing_amd/lib/libpt_phase.so python3 "$R/tools/tor_probe.py" > "$O/phase_tor.log" 2>&1
 PT_HIP_LIB=$R/path-tracing_amd/lib/libpt_phase.so python3 "$R/tools/c5_probe.py" 64,195 > "$O/phase_x64_x195.log" 2>&1
 echo "phase timers done"
+# dynamic instruction profile (tools/asm_profile.py): instrumented code object, execution counters per straight-line run
+PT_BLOCKPROF_OUT=$O/blockprof_tor python3 "$R/tools/blockprof_run.py" tor 8 > "$O/blockprof_tor.log" 2>&1
+PT_BLOCKPROF_OUT=$O/blockprof_x64 python3 "$R/tools/blockprof_run.py" x64 4 > "$O/blockprof_x64.log" 2>&1
+echo "block profile done"
 tail -c 400 "$O/bench_1gpu.json"
