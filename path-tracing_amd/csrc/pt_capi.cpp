@@ -408,8 +408,6 @@ static int render_device_impl(pt_scene *scene, const pt_render_params *p, float 
     a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
     a.error = p->error; a.seed = p->seed;
     a.blocks_x = (p->width + pt::kTileW - 1) / pt::kTileW;
-    // Scheduler: cut the pass range into chunks so that the launch has enough work items to balance its tail
-    // (about 24 per wave slot of the chip), but keep chunks of at least 4 passes.
     const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
     if (n_tiles == 0) {
         if (stats) {
@@ -418,15 +416,22 @@ static int render_device_impl(pt_scene *scene, const pt_render_params *p, float 
         }
         return PT_OK;
     }
+    // Scheduler: cut the pass range into chunks so that the tail of the launch is balanced with small work items.  A tile's
+    // chunks run in order and each re-reads and re-writes the tile's accumulators, so there should be few of them: chunk c
+    // takes 3/4 of the passes that are left (256 passes: 192 + 48 + 16), the last one at least 4 and less than 32.
     const uint32_t slots = static_cast<uint32_t>(scene->cu_count) * 4u * 6u;   // CUs x SIMDs x waves per SIMD of this kernel
-    uint32_t per_slot = 24u;
+    uint32_t n_chunks = 1;
+    int32_t chunk_passes = 0;
+    if (n_tiles >= slots / 2u)
+        while (n_chunks < 6u && (p->pass_count >> (2u * n_chunks)) >= 8) ++n_chunks;
 #ifdef PT_TEST_HOOKS
-    if (g_items_per_slot > 0) per_slot = static_cast<uint32_t>(g_items_per_slot);   // scheduler tuning, test build only
+    if (g_items_per_slot > 0) {   // scheduler tuning, test build only: equal chunks, about items_per_slot work items per wave slot
+        n_chunks = (static_cast<uint32_t>(g_items_per_slot) * slots + n_tiles - 1u) / n_tiles;
+        n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
+        chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
+        n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
+    }
 #endif
-    uint32_t n_chunks = (per_slot * slots + n_tiles - 1u) / n_tiles;
-    n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
-    const int32_t chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
-    n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
     if (static_cast<unsigned long long>(n_tiles) * n_chunks > 0x7fffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "too many work items");
     if (scene->has_prev && scene->prev_stream != stream) PT_HIP_TRY(hipStreamWaitEvent(stream, scene->ev_done, 0));
     if (scene->sched_words < 1 + static_cast<size_t>(n_tiles)) {

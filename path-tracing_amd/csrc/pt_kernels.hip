@@ -41,7 +41,13 @@ constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per w
 // Capacity of the two wave-private work queues.  Small scenes (Tor.obj) keep them small so that 5 KB of LDS per wave
 // leaves room for 6+ waves per SIMD; scenes with thousands of triangles get deep queues (fuller rounds) and pay with
 // occupancy, which matters less there.
-struct SmallQueues { static constexpr int kNodeStack = 96, kPairQueue = 144, kFiltered = 1; };
+#ifndef PT_SMALL_NODES
+#define PT_SMALL_NODES 160   // 96 / 144: 4 x the rounds that do not fit (partial commits), -0.9 %; LDS still allows 6 waves per SIMD
+#endif
+#ifndef PT_SMALL_PAIRS
+#define PT_SMALL_PAIRS 256
+#endif
+struct SmallQueues { static constexpr int kNodeStack = PT_SMALL_NODES, kPairQueue = PT_SMALL_PAIRS, kFiltered = 1; };
 #ifndef PT_BIG_NODES
 #define PT_BIG_NODES 384      // measured on the 16 398- and 49 934-triangle scenes: 832 / 512 (4 waves per SIMD) is 4 % slower,
 #endif
@@ -70,7 +76,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         const unsigned long long p1 = static_cast<unsigned long long>(c2) * 0xCD9E8D57u;
         const uint32_t h0 = static_cast<uint32_t>(p0 >> 32), l0 = static_cast<uint32_t>(p0);
         const uint32_t h1 = static_cast<uint32_t>(p1 >> 32), l1 = static_cast<uint32_t>(p1);
-        c0 = h1 ^ c1 ^ k0;
+        c0 = __builtin_amdgcn_bitop3_b32(h1, c1, k0, 0x96);   // three-way xor in one instruction (the compiler emits two v_xor_b32)
         c1 = l1;
         c2 = h0 ^ c3 ^ k1;
         c3 = l0;
@@ -1003,8 +1009,17 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_W
     if (lane == 0) item = atomicAdd(&a.sched[0], 1u);
     item = __builtin_amdgcn_readfirstlane(item);
     const uint32_t tile = item % a.n_tiles, chunk = item / a.n_tiles;
-    const int pass_first = a.pass_begin + static_cast<int>(chunk) * a.chunk_passes;
-    const int pass_last = min(a.pass_begin + a.pass_count, pass_first + a.chunk_passes);
+    // chunk_passes > 0: equal chunks.  chunk_passes == 0: chunk c covers passes [P - (P >> 2c), P - (P >> 2(c+1))) of the launch's P
+    // (3/4 of what is left each time, the last chunk takes the rest): the tail of the launch is balanced with small items while a
+    // tile's accumulators make few round trips to memory (3 chunks at 256 passes: 192 + 48 + 16).
+    int pass_first, pass_last;
+    if (a.chunk_passes > 0) {
+        pass_first = a.pass_begin + static_cast<int>(chunk) * a.chunk_passes;
+        pass_last = min(a.pass_begin + a.pass_count, pass_first + a.chunk_passes);
+    } else {
+        pass_first = a.pass_begin + (a.pass_count - (a.pass_count >> (2u * chunk)));
+        pass_last = a.pass_begin + (chunk + 1 < a.n_chunks ? a.pass_count - (a.pass_count >> (2u * (chunk + 1u))) : a.pass_count);
+    }
     if (chunk > 0) {
         if (lane == 0) {
             while (__hip_atomic_load(&a.sched[1 + tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) __builtin_amdgcn_s_sleep(8);

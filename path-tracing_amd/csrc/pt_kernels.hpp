@@ -37,7 +37,7 @@ struct RenderArgs {
     int32_t blocks_x;                   // ceil(width / 8)
     uint32_t *sched;                    // [0] ticket counter, [1 + tile] chunks of that tile already published; zeroed per launch
     uint32_t n_tiles, n_chunks;         // work items = n_tiles * n_chunks, chunk-major
-    int32_t chunk_passes;               // passes per chunk
+    int32_t chunk_passes;               // passes per chunk; 0 = geometric chunks (see the kernel)
     int32_t vec_ok;                     // sum / sum2 / count are 16-byte aligned and width % 4 == 0: 16-byte write-back allowed
     float r_org;                        // origins with a component beyond this are outside the cull margins' envelope
     int32_t may_leave_envelope;         // 0: no triangle of this scene can be hit outside the envelope, the integrator skips the test
