@@ -7,7 +7,8 @@
 //             loads and used straight from SGPRs.  Small triangles hang under a hierarchy: in scenes of up to 2048 triangles
 //             an 8-ary tree of bounding spheres per connected group, in bigger ones ONE tree of quantised boxes (64-byte
 //             nodes) over all of them.  Either tree is walked with a wave-wide LIFO of (ray, node) work items in LDS, dealt out
-//             evenly: lane l expands the l-th item whoever's ray it is.  The box walk also drops nodes entered beyond the
+//             evenly: lane l expands the l-th item whoever's ray it is; the queues are filled through a DPP prefix sum over the
+//             lanes' survivor counts (one LDS store per entry, totals for the capacity checks for free).  The box walk also drops nodes entered beyond the
 //             ray's best hit so far.  Every test is CONSERVATIVE with respect to the reference's Triangle::Intersect
 //             (triangles.h:48-73): it may only say "cannot be a hit".  Survivors become (ray, slot) pairs in a second LDS queue.
 //   2. EXACT  the pairs (about 1.5 per ray) are dealt out evenly as well; each runs the reference's arithmetic operation
@@ -16,6 +17,9 @@
 //             closest-hit choice are bit-identical to the CPU path.
 //   3. SHADE  Material::Process + the three lobes (material.h:36-102), Ray::Reflect (ray.h:45-50), the tile's accumulators
 //             (material.h:74-77) in LDS, counter-based Philox4x32-10 randoms keyed by (seed | pixel, pass, segment).
+//
+// The kernel is bound by instruction issue -- its time follows the number of instructions its waves execute, vector or scalar
+//  -- so the code below is written for few instructions, not for few memory accesses or many waves.
 //
 // Everything that decides a result is plain IEEE binary32/binary64 arithmetic (float sqrt and reciprocal through
 // pt_fastfp.hpp: shorter sequences, verified against the correctly rounded result for every float of their range); only

@@ -15,7 +15,8 @@ instruction run".  This tool produces exactly that:
 
 The inserted code uses registers the kernel does not (v110.. , s[100:101]) and saves / restores EXEC; it changes no
 flag the surrounding code reads (s_mov does not write SCC; VCC is untouched after the prologue).  Waits only get longer
-(an extra LDS operation in flight).  tools/blockprof.sh drives the whole thing.
+(an extra LDS operation in flight).  `make -C path-tracing_amd/csrc blockprof` builds the instrumented code object and
+libpt_blockprof.so, tools/blockprof_run.py renders a frame through them, tools/collect_profiles.py writes the reports.
 """
 import argparse
 import collections
@@ -32,7 +33,6 @@ def instrument(args):
     kernels = args.kernels.split(",")
     out, maps = [], {}
     cur_kernel, run_id, cur_loc, runs = None, 0, None, None
-    pending_counter = False
     lines = open(args.asm).read().split("\n")
     i = 0
 
