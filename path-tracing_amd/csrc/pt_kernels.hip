@@ -669,12 +669,14 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                         auto test = [&](auto per_c) {
                             constexpr uint32_t kPer = decltype(per_c)::value;
 #pragma unroll
-                            for (uint32_t i = 0; i < kPer; ++i) {
-                                if (c0 + i * cstep < nchild) {
-                                    const float4 sp = cs[i * cstep];
-                                    m |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << i) : 0u;
-                                }
+                            for (uint32_t i = 0; i < kPer; ++i) {   // no bounds test per sphere: the table is padded (pt_scene.cpp) ...
+                                const float4 sp = cs[i * cstep];
+                                m |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << i) : 0u;
                             }
+                            // ... and the results beyond the level's last node are dropped here
+                            const uint32_t left = nchild > c0 ? nchild - c0 : 0u;
+                            const uint32_t n_ok = min((left + cstep - 1u) >> (clev == 0 ? 0u : sh), kPer);
+                            m &= (1u << n_ok) - 1u;
                         };
                         if (per == 1u) test(std::integral_constant<uint32_t, 1>());
                         else if (per == 2u) test(std::integral_constant<uint32_t, 2>());

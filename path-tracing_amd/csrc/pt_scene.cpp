@@ -1077,7 +1077,8 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         out.clusters.push_back(cd);
     }
     // keep the tables non-empty and padded so that speculative wide scalar loads stay inside the allocation
-    for (int k = 0; k < 16; ++k) out.spheres.push_back(never);
+    // (the root round of the kernel reads up to 8 x 64 records from a level's start without a bounds test and masks afterwards)
+    for (int k = 0; k < 16 + 8 * 64; ++k) out.spheres.push_back(never);
     for (int k = 0; k < 4; ++k) { CullRec c; std::memset(&c, 0, sizeof c); out.bary.push_back(c); }
 
     // ---- big scenes: a barycentric record for every triangle, used to thin the (ray, triangle) pairs before the exact test
