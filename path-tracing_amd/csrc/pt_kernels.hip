@@ -417,18 +417,17 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
 // t = (org.x + q step - o.x) / d.x = A q + B with A = step / d.x, B = (org.x - o.x) / d.x, one fma per plane.
 // CONSERVATIVE: every computed t is within E = err (|B| + 255 |A|) of its exact value (rcp 1 ulp, one product, the
 // subtraction of the allowance, one fma: < 3.6e-7 relative to the operands' magnitudes; err = 5e-7), the boxes were
-// rounded outward on the host, and a child is dropped only if its interval misses [0, t_best] by more than 2E.  A zero direction component is replaced by 1e-30 of
-// the same sign: the ray then misses a slab it starts outside of by an astronomically large t and spans one it starts in.
+// rounded outward on the host, and a child is dropped only if its interval misses [0, t_best] by more than 2E.  A direction
+// component of exactly zero (or too small for its reciprocal) makes A and B infinite: the allowance becomes infinite, every entry
+// plane -inf or NaN, and every child of the node is kept (max / min skip NaNs, the final comparison is written so that a NaN keeps)
+// -- conservative, and rare enough (no camera ray, no sampled direction has an exactly zero component) not to be worth the nine
+// instructions per node that clamping the component to 1e-30 cost.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return static_cast<float>((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
-__device__ __forceinline__ float safe_rcp(float d) {
-    const float m = __builtin_fmaxf(__builtin_fabsf(d), 1.0e-30f);
-    return __builtin_amdgcn_rcpf(__builtin_copysignf(m, d));
-}
 __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
                                                       float t_best, float err) {
     const float step = __uint_as_float((q0.w & 0xFFu) << 23);
-    const float ix = safe_rcp(r.dx), iy = safe_rcp(r.dy), iz = safe_rcp(r.dz);
+    const float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
     const float ax = step * ix, ay = step * iy, az = step * iz;
     const float bx = (__uint_as_float(q0.x) - r.ox) * ix, by = (__uint_as_float(q0.y) - r.oy) * iy, bz = (__uint_as_float(q0.z) - r.oz) * iz;
     const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx), __builtin_fabsf(by)), __builtin_fabsf(bz));

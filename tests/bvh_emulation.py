@@ -28,6 +28,8 @@ def fma(a, b, c):
 
 def children_kept(t, node, o, d, t_best, err):
     """Kept-children masks [n_rays, 8] of nodes `node` [n_rays] for rays (o, d) [n_rays, 3] float32."""
+    # (the kernel takes the plain reciprocal: a zero component gives infinite planes and keeps every child; clamping it to
+    # 1e-30 here models a cull that is at least as strict, so what this restatement keeps the kernel keeps as well)
     m = np.maximum(np.abs(d), F(1e-30))
     inv = (F(1) / np.copysign(m, d)).astype(np.float32)
     step = t["step"][node][:, None]
