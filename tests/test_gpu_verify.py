@@ -108,3 +108,26 @@ def test_every_segment_of_random_scenes(tmp_path, vlib, seed, n_small, n_large, 
     # a candidate (before they did, this test found them: 10-14 of 5 million segments differed).
     assert st["verify_checked"] == st["segments"] > 640 * 360 * 8
     assert st["verify_mismatches"] == 0
+
+
+def test_smallest_queues_find_every_hit(models_dir, tmp_path):
+    """libpt_verify_tiny.so = the verification build with the work queues at their smallest legal sizes (64-entry node stack,
+    128-entry pair queue, small and big scenes): almost every round of the big-scene walk then takes the rare paths --
+    the queue does not fit, a prefix of the lanes commits, exact rounds are forced early -- and every segment is still
+    compared with the all-triangles loop.  The frames must be the shipped library's frames."""
+    path = os.path.join(os.path.dirname(pt.VERIFY_LIB_PATH), "libpt_verify_tiny.so")
+    L = pt.load_library(path)
+    L.pt_test_set_mutation(b"reset", 0.0)
+    v = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=L)
+    s, s2, c, st = v.render_host(960, 540, 16, 8, error=-1.0)
+    assert st["verify_checked"] == st["segments"] > 0 and st["verify_mismatches"] == 0
+    assert st["partial_commit_rounds"] > 1000
+    g = pt.Scene.load_obj(models_dir, "Tor.obj", device=0)
+    assert _digest(*g.render_host(960, 540, 16, 8, error=-1.0, want_stats=False)[:3]) == _digest(s, s2, c)
+    d, name = _replica(tmp_path, 64)
+    v = pt.Scene.load_obj(d, name, device=0, library=L)
+    s, s2, c, st = v.render_host(960, 540, 2, 8, error=-1.0)
+    assert st["verify_checked"] == st["segments"] > 0 and st["verify_mismatches"] == 0
+    assert st["partial_commit_rounds"] > 100000
+    g = pt.Scene.load_obj(d, name, device=0)
+    assert _digest(*g.render_host(960, 540, 2, 8, error=-1.0, want_stats=False)[:3]) == _digest(s, s2, c)
