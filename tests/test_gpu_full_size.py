@@ -71,3 +71,15 @@ def test_image_is_plausible(frame):
     left, right = img[300:800, 20:120].mean((0, 1)), img[300:800, 1800:1900].mean((0, 1))
     assert left[2] > 2 * left[1] and right[1] > 2 * right[2]       # red wall on the left, green on the right (B,G,R order)
     assert 0.5 < disp[2] < 0.9 and disp[0] < 1.5
+
+
+def test_pass_chunks_are_geometric(frame):
+    """The scheduler cuts a full-size launch into few, geometrically shrinking chunks of passes (192 + 48 + 16 at 256 spp):
+    each chunk costs a round trip of the tile's accumulators to memory, the small last ones balance the tail.  A frame too
+    small to fill the chip is not cut at all.  (That the cut does not change a bit is what the digest tests above show.)"""
+    g, s, s2, c, st = frame
+    assert st["n_chunks"] == 2                                            # 64 passes: 48 + 16
+    assert g.render_host(W, H, 256, 1)[3]["n_chunks"] == 3                # 192 + 48 + 16
+    assert g.render_host(W, H, 1024, 0)[3]["n_chunks"] == 4               # 768 + 192 + 48 + 16
+    assert g.render_host(W, H, 20, 1)[3]["n_chunks"] == 1                 # 20 >> 2 = 5 < 8: not worth a cut
+    assert g.render_host(256, 256, 256, 1)[3]["n_chunks"] == 1            # 1024 tiles for 6144 wave slots
