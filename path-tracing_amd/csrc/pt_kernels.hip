@@ -341,6 +341,7 @@ struct WaveLds {
     // The code that fills the queues relies on these minima (see push_pairs_any, drain_pairs and the tree walk):
     static_assert(Q::kPairQueue >= 128, "push_pairs_any publishes slices of up to 128 pairs");
     static_assert(!kPrefilter || Q::kFiltered >= 128, "the pre-filter appends up to 64 survivors to up to 63 waiting ones");
+    static_assert(!kPrefilter || Q::kFiltered >= PT_BIG_EXACT_AT - 1 + 64, "up to PT_BIG_EXACT_AT - 1 pairs wait when 64 survivors are appended");
     static_assert(Q::kNodeStack >= 64, "a round pops up to 64 nodes");
     uint32_t filtered[Q::kFiltered];   // pairs that survived the pre-filter, waiting for a full exact round
     unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
