@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 // triangles; CullTables::may_leave_envelope): every segment's origin is then checked.  A compile-time choice because the
 // mere presence of the rare path costs the common scenes 2 % (measured), whether or not it ever runs.
 template <bool SKY, bool BIG, bool STATS, bool ENV>
-__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STATS ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
