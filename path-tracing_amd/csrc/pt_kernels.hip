@@ -1171,9 +1171,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
                     const float4 m0v = reinterpret_cast<const float4 *>(a.mats + mi)[0];   // kd, chance0
                     const float4 m1v = reinterpret_cast<const float4 *>(a.mats + mi)[1];   // ks, chance1
                     const int4 m2v = reinterpret_cast<const int4 *>(a.mats + mi)[2];       // n_lobes, kind0, kind1
-                    uint32_t w0, w1, w2, w3;
-                    philox4x32_10(opaque(gpix), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth), 0u, a.seed, kPhiloxKey1,
-                                  w0, w1, w2, w3);
+                    // On a path's last segment the random words only matter where they choose between an emissive lobe and
+                    // another one (see below: nothing else of that segment survives it).
+                    uint32_t w0 = 0, w1 = 0, w2 = 0, w3;
+                    if (depth + 1 < mrr || (m2v.x >= 2 && (m2v.y == 0 || m2v.z == 0)))
+                        philox4x32_10(opaque(gpix), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth), 0u, a.seed, kPhiloxKey1,
+                                      w0, w1, w2, w3);
                     int kind;
                     if (m2v.x == 0) {
                         kind = -1;
@@ -1203,6 +1206,10 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
                     } else {
                         // Both scattering lobes end in Ray::Reflect (ray.h:45-50): the lobe-specific part leaves the new direction
                         // (not yet normalised by Reflect) and the throughput factor, the common tail runs once per wave.
+                        // A path's last segment (depth + 1 == mrr: all live lanes of a wave reach it together) can only contribute
+                        // through the emissive lobe above: the ray a scattering lobe would produce is never traced
+                        // (Ray::IsValid, ray.h:52-54), so it is not computed either.
+                        if (depth + 1 < mrr) {
                         float rx, ry, rz, fr, fg, fb;
                         if (kind == 1) {   // glossy, material.h:83-85
                             const float dn = (pl.x * q.dx + pl.y * q.dy) + pl.z * q.dz;
@@ -1225,6 +1232,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
                         q.ox = px + pl.x * eps; q.oy = py + pl.y * eps; q.oz = pz + pl.z * eps;
                         q.dx = rx; q.dy = ry; q.dz = rz;
                         tr *= fr; tg *= fg; tb *= fb;
+                        }
                         ++depth;
                     }
                 }
