@@ -1034,8 +1034,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
-    const int x = static_cast<int>(tile % a.blocks_x) * kTileW + (lane % kTileW);
-    const int y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH + (lane / kTileW);
+    const int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTileW, tile_y0 = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;   // wave-uniform
+    const int x = tile_x0 + (lane % kTileW);
+    const int y = tile_y0 + (lane / kTileW);
     const bool in_image = x < a.width && y < a.row_end;
     const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
     const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
@@ -1091,7 +1092,10 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
             // x, y are made opaque once per pass so that their int->double conversions (and the doubles of width and
             // height) are redone here instead of being hoisted out of the pass loop, where they would occupy eight
             // VGPRs for the whole kernel (the compiler spilled them to scratch: ~1 GB of memory traffic per frame).
-            int xi = x, yi = y, wi = a.width, hi = a.height;
+            // (x and y themselves are rebuilt from the lane number and the tile's wave-uniform corner: kept in two VGPRs for the
+            // whole kernel they were spilled to scratch, a launch-time cost that doubled the time of a 256 x 256 frame)
+            int xi = tile_x0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) % kTileW), yi = tile_y0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) / kTileW);
+            int wi = a.width, hi = a.height;
             asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
             q.dx = static_cast<float>((xi + jx) / wi - 0.5f);
             q.dy = static_cast<float>(-(yi + jy) / hi + 0.5f);
@@ -1276,7 +1280,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
             *reinterpret_cast<int4 *>(a.count + base) = oc;
         }
     } else if (in_image) {
-        const size_t pe = static_cast<size_t>(y - a.row_begin) * a.width + x;   // recomputed: p would be spilled across the kernel
+        // recomputed from the tile's corner and the lane number: p, x or y kept across the kernel would be spilled
+        const uint32_t le = opaque(static_cast<uint32_t>(lane));
+        const size_t pe = static_cast<size_t>(tile_y + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x + static_cast<int>(le % kTileW));
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             a.sum[3 * pe + k] = lds.acc[k][lane];
