@@ -1094,7 +1094,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
             // VGPRs for the whole kernel (the compiler spilled them to scratch: ~1 GB of memory traffic per frame).
             // (x and y themselves are rebuilt from the lane number and the tile's wave-uniform corner: kept in two VGPRs for the
             // whole kernel they were spilled to scratch, a launch-time cost that doubled the time of a 256 x 256 frame)
-            int xi = tile_x0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) % kTileW), yi = tile_y0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) / kTileW);
+            // (the big-scene kernel has the registers to keep them: there the recomputation costs 2.6 %)
+            int xi = x, yi = y;
+            if constexpr (!BIG) {
+                xi = tile_x0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) % kTileW);
+                yi = tile_y0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) / kTileW);
+            }
             int wi = a.width, hi = a.height;
             asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
             q.dx = static_cast<float>((xi + jx) / wi - 0.5f);
@@ -1282,7 +1287,8 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
     } else if (in_image) {
         // recomputed from the tile's corner and the lane number: p, x or y kept across the kernel would be spilled
         const uint32_t le = opaque(static_cast<uint32_t>(lane));
-        const size_t pe = static_cast<size_t>(tile_y + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x + static_cast<int>(le % kTileW));
+        const size_t pe = BIG ? static_cast<size_t>(y - a.row_begin) * a.width + x
+                              : static_cast<size_t>(tile_y + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x + static_cast<int>(le % kTileW));
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             a.sum[3 * pe + k] = lds.acc[k][lane];
