@@ -201,6 +201,13 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.m0_quad = cc.m0_quad; a.t_guard = cc.t_guard;
     a.r_org = scene->cull.host.r_org;
     a.may_leave_envelope = scene->cull.host.may_leave_envelope ? 1 : 0;
+    a.last_segment_filter = 1;
+#ifdef PT_TEST_HOOKS
+    if (pt::g_cull_mutation.no_last_segment_filter) a.last_segment_filter = 0;
+#endif
+    a.emis_clusters = scene->cull.host.emis_clusters;
+    a.emis_large_w0 = scene->cull.host.emis_large_w0;
+    a.emis_bvh = scene->cull.host.emis_bvh ? 1u : 0u;
 }
 
 // No exception may cross the C boundary: allocation failures and anything else become status codes.
@@ -917,6 +924,7 @@ int pt_test_set_mutation(const char *family, double value) {
     else if (f == "box") m.box = value;
     else if (f == "box_err") m.box_err = value;
     else if (f == "no_absorb") m.no_absorb = value != 0;
+    else if (f == "no_last_segment_filter") m.no_last_segment_filter = value != 0;
     else if (f == "order_mode") m.order_mode = static_cast<int>(value);
     else if (f == "bvh_fill") m.bvh_fill = value;
     else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);

@@ -474,9 +474,13 @@ __device__ __forceinline__ unsigned long long brute_force_key(const RenderArgs &
     return best;
 }
 
-template <bool ENV, class Lds, class Stats>
+// emis_flag (wave-uniform, honoured only by instantiations with EMIS): search only where emitters are (RenderArgs::emis_*) --
+// the closest hit among a SUPERSET of the emitters, which is all the caller needs to know whether the ray's closest hit can be
+// one (see the last segment in the kernel).
+template <bool ENV, bool EMIS, class Lds, class Stats>
 __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray &q, bool live, bool in_envelope, int lane,
-                                            float eps, float &best, int &hit, const ExactRec *&hit_rec, Stats &st) {
+                                            float eps, float &best, int &hit, const ExactRec *&hit_rec, Stats &st, bool emis_flag = false) {
+    const bool emis_only = EMIS && emis_flag;
     // `valid` below = rays that go through the culling hierarchy; live rays outside the envelope its margins were derived
     // for get every slot as a candidate instead (rare: see the caller).
     const bool valid = live && in_envelope;
@@ -624,6 +628,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     constexpr int kDescWords = sizeof(ClusterDesc) / 4;
     for (int cl = 0; cl < a.n_clusters; ++cl) {
         const ConstF cp = clusters + kDescWords * cl;
+        if (emis_only && cl < 32 && !((a.emis_clusters >> cl) & 1u)) continue;   // no emitter in this cluster
         const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
         // (the large class is tested triangle by triangle anyway, and its bounding sphere is the scene's: nothing to gain from it)
         const bool pc = kind == 0 ? valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q) : valid;
@@ -836,6 +841,21 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 uint32_t m = 0;
                 const uint32_t cnt32 = min(left, 32u);
                 const uint32_t pair_bits = 0x55555555u & (cnt32 >= 32u ? 0xFFFFFFFFu : ((1u << cnt32) - 1u));
+                if (emis_only && n_words == 1) {   // only the records that hold an emitter (the light of a room: one quad)
+                    for (uint32_t rest = (a.emis_large_w0 | (a.emis_large_w0 >> 1)) & pair_bits; rest != 0; rest &= rest - 1) {
+                        const uint32_t k0 = __builtin_ctz(rest);
+                        if ((quads >> k0) & 1u) {
+                            const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
+                            m |= (~rej & 3u) << k0;
+                        } else {
+                            for (uint32_t j = 0; j < 2; ++j) {
+                                const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
+                                m |= rej ? 0u : (1u << (k0 + j));
+                            }
+                        }
+                    }
+                    m &= a.emis_large_w0;
+                } else
                 if (quads == pair_bits) {   // every record of the word is a quad (the walls of a room): no per-record dispatch
                     for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {
                         const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
@@ -868,7 +888,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         // The large class above went first and is tested right away, so that lds.best already holds a hit (the wall behind
         // everything, in a closed room) when the walk starts: a node whose box the ray enters beyond its best hit so far is
         // dropped, and because pairs are tested as soon as 64 are waiting, closer hits keep shrinking the rest of the walk.
-        if (a.n_bvh > 0) {
+        if (a.n_bvh > 0 && !(emis_only && a.emis_bvh == 0u)) {
             flush_pending();
             drain_pairs(0);
             if (n_filtered > 0) {
@@ -1131,7 +1151,22 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
             bool inside = true;
             if constexpr (ENV)
                 inside = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.ox), __builtin_fabsf(q.oy)), __builtin_fabsf(q.oz)) <= a.r_org;
-            closest_hit<ENV>(a, lds, q, valid, inside, lane, eps, best, hit, hit_rec, wst);
+            // A path's last segment (depth + 1 == mrr; the live lanes of a wave reach it together) can only contribute by hitting
+            // an emitter, and whatever else it hits is never looked at (no next ray, statistics not requested, no skybox).  So
+            // the search runs among the emitters alone first -- for Tor.obj one quad record instead of seven walls and a torus --
+            // and the full search, which decides whether the emitter really is the closest hit, only for rays that hit one.
+            bool searched = valid;
+            constexpr bool kLastSegmentFilter = !STATS && !SKY && !BIG;   // (big scenes: the flag's scalar registers cost more than it saves)
+            bool emis_phase = false;
+            if constexpr (kLastSegmentFilter) emis_phase = a.last_segment_filter != 0u && __all(!valid || depth + 1 >= mrr);
+            for (;;) {
+                closest_hit<ENV, kLastSegmentFilter>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase);
+                if (!emis_phase) break;
+                emis_phase = false;
+                searched = searched && hit >= 0;
+                if (!__any(searched)) break;
+            }
+            if (!searched) hit = -1;   // (a ray of the last segment that met no emitter ends like a miss, contributing nothing)
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
             if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
@@ -1346,7 +1381,7 @@ __global__ __launch_bounds__(kBlock, BIG ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_
     int hit;
     const ExactRec *hit_rec;
     WaveStats st;
-    closest_hit<true>(a, lds, q, valid, inside, lane, a.eps, best, hit, hit_rec, st);
+    closest_hit<true, false>(a, lds, q, valid, inside, lane, a.eps, best, hit, hit_rec, st);
     if (valid) {
         hit_index[i] = hit;
         hit_t[i] = best;

@@ -41,6 +41,10 @@ struct RenderArgs {
     int32_t vec_ok;                     // sum / sum2 / count are 16-byte aligned and width % 4 == 0: 16-byte write-back allowed
     float r_org;                        // origins with a component beyond this are outside the cull margins' envelope
     int32_t may_leave_envelope;         // 0: no triangle of this scene can be hit outside the envelope, the integrator skips the test
+    // A path's last segment (depth + 1 == mrr) can only contribute by hitting an emitter: the statistics-free, skybox-free
+    // instantiations search the emitters alone first (CullTables::emis_*) and run the full search only for rays that hit one.
+    uint32_t last_segment_filter;       // 0 = off
+    uint32_t emis_clusters, emis_large_w0, emis_bvh;
 #ifdef PT_BLOCK_PROFILE
     uint32_t *blockprof;                // diagnostic build only (tools/asm_profile.py): execution counters of the instrumented code object
 #endif

@@ -1131,6 +1131,30 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     double tga = 4096.0 * r_org;
     if (a_max_all > 0) tga = std::min(tga, 1.0e6 / a_max_all);
     out.cc_all.t_guard = static_cast<float>(tga);
+
+    // ---- where the emitters are (a material with Ke != 0 is the emissive lobe alone, material.h:58-106)
+    auto emits = [&](uint32_t slot) {
+        const uint32_t t = slot < out.slot_tri.size() ? out.slot_tri[slot] : kNoTriangle;
+        if (t == kNoTriangle) return false;
+        const float *m = &s.mat[10 * static_cast<size_t>(s.tri_mat[t])];
+        return m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f;
+    };
+    out.emis_clusters = 0;
+    out.emis_large_w0 = 0xFFFFFFFFu;
+    for (size_t c = 0; c < out.clusters.size(); ++c) {
+        const ClusterDesc &cd = out.clusters[c];
+        bool any = false;
+        for (uint32_t k = 0; k < cd.n_tri; ++k) any = any || emits(cd.first_tri + k);
+        if (c >= 32 || any) out.emis_clusters |= c < 32 ? (1u << c) : 0u;
+        if (cd.kind == 1u && cd.n_tri <= static_cast<uint32_t>(kChunk)) {
+            out.emis_large_w0 = 0;
+            for (uint32_t k = 0; k < cd.n_tri; ++k) out.emis_large_w0 |= emits(cd.first_tri + k) ? (1u << k) : 0u;
+        }
+    }
+    if (out.clusters.size() > 32) out.emis_clusters = 0xFFFFFFFFu;   // (small scenes have at most 10 clusters)
+    out.emis_bvh = false;
+    if (!out.bvh.empty())
+        for (uint32_t k = 0; k < static_cast<uint32_t>(n_small_slots); ++k) out.emis_bvh = out.emis_bvh || emits(k);
 }
 
 }  // namespace pt

@@ -125,6 +125,11 @@ struct CullTables {
     float eps = 0;
     float r_org = 0;                 // the margins hold for ray origins with every |component| <= r_org
     bool may_leave_envelope = false; // some triangle can be "hit" at a point outside that envelope (near-degenerate triangles)
+    // Where the emitters are (triangles whose material has an emissive lobe): a path's LAST segment can only contribute by
+    // hitting one, so the integrator first searches among them alone (pt_kernels.hip: `emis_only`).
+    uint32_t emis_clusters = 0xFFFFFFFFu;  // bit c: cluster c (< 32) holds an emitter; clusters >= 32 count as holding one
+    uint32_t emis_large_w0 = 0xFFFFFFFFu;  // large class of at most 32 slots: its emitters (all ones if the class is larger)
+    bool emis_bvh = true;                  // the box tree of a big scene holds an emitter
 };
 
 #ifdef PT_TEST_HOOKS
@@ -133,6 +138,7 @@ struct CullTables {
 struct CullMutation {
     double sphere_r2 = 1, m0 = 1, k12 = 1, a_max = 1, quad_slack = 1, box = 1, box_err = 1;
     int no_absorb = 0;
+    int no_last_segment_filter = 0;   // integrator: 1 = a path's last segment searches all triangles like every other segment
     double bvh_fill = 0.75;   // box tree: target fill of a node's children (builder tuning)
     int order_mode = 0;   // small-scene clusters: 0 = cheaper of (cells, patches), 1 = as filed, 2 = cells, 3 = patches
 };
