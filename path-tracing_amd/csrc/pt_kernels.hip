@@ -1159,7 +1159,35 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
             constexpr bool kLastSegmentFilter = !STATS && !SKY && !BIG;   // (big scenes: the flag's scalar registers cost more than it saves)
             bool emis_phase = false;
             if constexpr (kLastSegmentFilter) emis_phase = a.last_segment_filter != 0u && __all(!valid || depth + 1 >= mrr);
+            if constexpr (BIG && !STATS && !SKY) {
+                // Big scenes: the same idea without a second search.  The table builder keeps a big scene's emitters in the
+                // large class (pt_scene.cpp), so the conservative test of those records alone says which rays of the last
+                // segment can reach an emitter at all; only those are searched.
+                if (a.last_segment_filter != 0u && a.emis_bvh == 0u && a.n_clusters == 1 && __all(!valid || depth + 1 >= mrr)) {
+                    const ConstF cp = (ConstF)reinterpret_cast<uintptr_t>(a.clusters) + (sizeof(ClusterDesc) / 4) * (a.n_clusters - 1);
+                    const uint32_t n_large = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7], quads = ((ConstU)cp)[9];
+                    if (kind == 1u && n_large <= static_cast<uint32_t>(kChunk)) {
+                        float k1 = a.k1, k2 = a.k2, a_max = a.a_max, m0 = a.m0, m0q = a.m0_quad, t_guard = a.t_guard;
+                        asm volatile("" : "+v"(k1), "+v"(k2), "+v"(a_max), "+v"(m0), "+v"(m0q), "+v"(t_guard));
+                        const ConstF bp = (ConstF)reinterpret_cast<uintptr_t>(a.bary) + 12 * static_cast<size_t>(off);
+                        uint32_t m = 0;
+                        for (uint32_t rest = (a.emis_large_w0 | (a.emis_large_w0 >> 1)) & 0x55555555u; rest != 0; rest &= rest - 1) {
+                            const uint32_t k0 = __builtin_ctz(rest);
+                            if ((quads >> k0) & 1u) {
+                                m |= (~cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard) & 3u) << k0;
+                            } else {
+                                for (uint32_t j = 0; j < 2; ++j)
+                                    m |= cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard) ? 0u : (1u << (k0 + j));
+                            }
+                        }
+                        bool can_reach = (m & a.emis_large_w0) != 0u;
+                        if constexpr (ENV) can_reach = can_reach || !inside;   // (outside the margins' envelope nothing is culled)
+                        searched = valid && can_reach;
+                    }
+                }
+            }
             for (;;) {
+                if (BIG && !__any(searched)) break;
                 closest_hit<ENV, kLastSegmentFilter>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase);
                 if (!emis_phase) break;
                 emis_phase = false;

@@ -749,6 +749,18 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         const double reff = sphere_of(&i, 1, tmp);
         large[i] = !(reff < 0.12 * r_max);
     }
+    // A big scene's few emitters (the light of a room) join the large class whatever their size: their records alone then
+    // tell which rays of a path's last segment can still contribute (pt_kernels.hip, "last segment").
+    if (T > kBigSceneTriangles) {
+        auto emits = [&](int t) {
+            const float *m = &s.mat[10 * static_cast<size_t>(s.tri_mat[t])];
+            return m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f;
+        };
+        int n_emit = 0;
+        for (int i = 0; i < T; ++i) n_emit += emits(i);
+        if (n_emit <= 8)
+            for (int i = 0; i < T; ++i) if (emits(i)) large[i] = 1;
+    }
     // connected groups of small triangles (triangles sharing a vertex position): the objects of the scene
     UnionFind uf(T);
     {
