@@ -95,7 +95,7 @@ def instrument(args):
                         f"\tglobal_atomic_add v[114:115], v116, off offset:{256 * (j % 16)}"]
             out += ["\ts_waitcnt vmcnt(0)", line]
             continue
-        runs[-1].append([op, cur_loc[0] if cur_loc else -1, cur_loc[1] if cur_loc else 0])
+        runs[-1].append([op, cur_loc[0] if cur_loc else -1, cur_loc[1] if cur_loc else 0, line.split(";")[0].strip()[len(op):].strip()])
         out.append(line)
         if op.startswith("s_cbranch") or op == "s_branch":
             new_run()
@@ -148,6 +148,40 @@ def kind(op):
     return "vmem"
 
 
+# SIMD cycles one wave-instruction keeps its pipe busy, from tools/issue_cost.hip on an MI355X (profiles/r02_issue_cost.txt):
+# the plain fp32 / integer-add / logic operations run a wave in 2 cycles when every operand is a VGPR, a literal or an
+# inline constant; with a scalar-register operand, as DPP / SDWA, and for everything else (min / max, compares, selects,
+# conversions, shifts left, three-operand integer forms, 64-bit and fp64, integer multiplies, lane access) it is 4;
+# reciprocal / square root 8.  Scalar instructions take 4 cycles on the scalar pipe, which runs beside the vector pipe.
+FAST_VALU = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mov_b32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32",
+             "v_subrev_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_bitop3_b32",
+             "v_mul_lo_u16", "v_mul_legacy_f32"}
+SLOW8_VALU = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_rcp_iflag_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32"}
+SLOW16_VALU = {"v_rcp_f64", "v_rsq_f64", "v_sqrt_f64"}
+
+
+def pipe_cycles(op, operands):
+    """(pipe, cycles) of one wave-instruction."""
+    k = kind(op)
+    if k == "valu":
+        base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+        if base in SLOW8_VALU:
+            return "valu", 8.0
+        if base in SLOW16_VALU:
+            return "valu", 16.0
+        scalar_operand = re.search(r"(?<![\w.])(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|exec_lo|exec_hi|m0|ttmp\d+)\b", operands) is not None
+        if base in FAST_VALU and not scalar_operand and not op.endswith(("_dpp", "_sdwa")) and "row_" not in operands and "sel:" not in operands:
+            return "valu", 2.0
+        return "valu", 4.0
+    if k in ("salu", "branch"):
+        return "salu", 4.0
+    if k in ("nop", "wait"):
+        return "salu", 0.7
+    if k == "lds":
+        return "lds", 17.0 if "write" in op or "add" in op or "min" in op or "max" in op else 9.0
+    return k, 4.0
+
+
 def report(args):
     mp = json.load(open(args.map))
     runs = mp["runs"][args.kernel]
@@ -161,17 +195,32 @@ def report(args):
     per_kind = collections.Counter()
     per_op = collections.Counter()
     total = 0
+    line_cycles = collections.Counter()      # vector-pipe cycles per source line
+    pipe_total = collections.Counter()
+    scalar_operand_valu = 0
     for k, ins in enumerate(runs):
         c = cnt.get(k, 0)
-        for op, f, l in ins:
+        for rec in ins:
+            op, f, l = rec[0], rec[1], rec[2]
             per_line[(f, l)] += c
             per_kind[kind(op)] += c
             per_op[op] += c
             total += c
+            if len(rec) > 3:
+                pipe, cyc = pipe_cycles(op, rec[3])
+                pipe_total[pipe] += c * cyc
+                if pipe == "valu":
+                    line_cycles[(f, l)] += c * cyc
+                    base = re.sub(r"_(e32|e64)$", "", op)
+                    if cyc == 4.0 and base in FAST_VALU:
+                        scalar_operand_valu += c
     ws = args.wave_segments or 1
     print(f"kernel {args.kernel}: {total} instructions executed, {total / ws:.1f} per wave-segment ({ws} wave-segments)")
     print("by kind (per wave-segment): " + "  ".join(f"{k} {v / ws:.1f}" for k, v in per_kind.most_common()))
     print("top opcodes: " + "  ".join(f"{k} {v / ws:.1f}" for k, v in per_op.most_common(25)))
+    if pipe_total:
+        print("pipe cycles per wave-segment (cost table of tools/issue_cost.hip): " + "  ".join(f"{k} {v / ws:.0f}" for k, v in pipe_total.most_common())
+              + f"   [fp32 / add / logic instructions slowed to 4 cycles by a scalar operand, DPP or SDWA: {scalar_operand_valu / ws:.1f} per wave-segment]")
     regions = []
     if args.regions:
         src_lines = open(args.source).read().split("\n")
@@ -208,21 +257,36 @@ def report(args):
         else:
             other_files[fname] += c
     unassigned = other_files
+    region_cycles = collections.Counter()
+    main_cycles_total = sum(line_cycles.values()) or 1
+    for (f, l), cy in line_cycles.items():
+        fname = (files.get(f, "?") if f >= 0 else "?").split("/")[-1]
+        if regions and fname == main_name and l != 0:
+            for a, b, name in regions:
+                if a <= l <= b:
+                    region_cycles[name] += cy
+                    break
+        elif regions and fname != main_name:
+            region_cycles["[" + fname + "]"] += cy
+        elif regions:
+            region_cycles["(no source line: compiler-generated, inlined helpers without locations)"] += cy
     if regions:
-        print("\nby region (instructions per wave-segment, share):")
+        print("\nby region (instructions per wave-segment, share of instructions; vector-pipe cycles per wave-segment, share of those):")
         for name, c in per_region.most_common():
-            print(f"  {name:34s} {c / ws:8.1f}  {100.0 * c / total:5.1f} %")
+            cy = region_cycles.get(name, 0)
+            print(f"  {name:34s} {c / ws:8.1f}  {100.0 * c / total:5.1f} %   {cy / ws:8.0f}  {100.0 * cy / main_cycles_total:5.1f} %")
         for fname, c in other_files.most_common():
-            print(f"  {'[' + fname + ']':34s} {c / ws:8.1f}  {100.0 * c / total:5.1f} %")
+            cy = region_cycles.get("[" + fname + "]", 0)
+            print(f"  {'[' + fname + ']':34s} {c / ws:8.1f}  {100.0 * c / total:5.1f} %   {cy / ws:8.0f}  {100.0 * cy / main_cycles_total:5.1f} %")
     print("\nhottest source lines:")
     for (f, l), c in per_line.most_common(args.top):
         fname = files.get(f, "?") if f >= 0 else "?"
-        print(f"  {fname.split('/')[-1]}:{l:<5d} {c / ws:8.1f}  {100.0 * c / total:5.1f} %")
+        print(f"  {fname.split('/')[-1]}:{l:<5d} {c / ws:8.1f}  {100.0 * c / total:5.1f} %   {line_cycles.get((f, l), 0) / ws:8.0f} cycles")
     if args.runs_out:
         with open(args.runs_out, "w") as fp:
             for k, ins in enumerate(runs):
                 c = cnt.get(k, 0)
-                lines = collections.Counter((f, l) for _, f, l in ins)
+                lines = collections.Counter((r[1], r[2]) for r in ins)
                 top = " ".join(f"{l}x{n}" for (f, l), n in lines.most_common(5) if f == 0)
                 fp.write(f"{k:4d} exec/ws {c / ws:8.3f} n={len(ins):4d} instr/ws {c * len(ins) / ws:8.1f} | {top}\n")
 
