@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--scenes", default="tor,x64,x195")
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--order-modes", default="")
+    ap.add_argument("--sweep", default="", help="test-hook knob and values, e.g. bvh_fill=0.6,0.75,1.0 (libpt_testhooks.so)")
     a = ap.parse_args()
     import torch
     import make_replicated_scene as M
@@ -39,13 +40,17 @@ def main():
     buf = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
     runs = [(name, None) for name in a.libs.split(",")]
+    knob = "order_mode"
     if a.order_modes:
         runs = [("testhooks", int(m)) for m in a.order_modes.split(",")]
+    if a.sweep:
+        knob, values = a.sweep.split("=")
+        runs = [("testhooks", float(v)) for v in values.split(",")]
     for name, mode in runs:
         L = pt.load_library(os.path.join(ROOT, "path-tracing_amd", "lib", f"libpt_{name}.so"))
         if mode is not None:
             L.pt_test_set_mutation(b"reset", 0.0)
-            L.pt_test_set_mutation(b"order_mode", float(mode))
+            L.pt_test_set_mutation(knob.encode(), float(mode))
         for sn in a.scenes.split(","):
             sc = pt.Scene.load_obj(*scenes[sn], device=0, library=L)
             p = pt.RenderParams(W, H, 0, H, 0, a.spp, 8, 1e-4, -1.0, 42)
@@ -64,7 +69,7 @@ def main():
             import hashlib
             digest = hashlib.sha1(buf.cpu().numpy().tobytes()).hexdigest()[:12]   # equal digests = bit-identical frames
             ws = max(1, st["wave_segments"])
-            print(f"{name}{'' if mode is None else ' order_mode=' + str(mode)} {sn}: {W * H * a.spp / ms[1] / 1e3:.1f} Msamples/s  kernel {ms[1]:.2f} ms  "
+            print(f"{name}{'' if mode is None else ' ' + knob + '=' + str(mode)} {sn}: {W * H * a.spp / ms[1] / 1e3:.1f} Msamples/s  kernel {ms[1]:.2f} ms  "
                   f"node rounds/wseg {st['wave_node_rounds'] / ws:.2f}  exact rounds/wseg {st['wave_exact_iterations'] / ws:.2f}  "
                   f"exact/seg {st['exact_tests'] / max(1, st['segments']):.3f}  partial {st['partial_commit_rounds']}  frame {digest}", flush=True)
             sc.close()
