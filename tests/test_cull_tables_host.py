@@ -280,3 +280,33 @@ def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path):
         node, child, ro, rd, tb = node[live], child[live], ro[live], rd[live], tb[live]
         levels += 1
     assert levels >= 3
+
+
+def test_big_scene_keeps_its_few_emitters_in_the_large_class(tmp_path, models_dir):
+    """pt_scene.cpp: a big scene's emitters (<= 8 triangles: the light of a room) join the large class whatever their size,
+    so that the kernel's last-segment test has their records; many emissive triangles stay under the box tree."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_replicated_scene as M
+    d = str(tmp_path) + "/"
+    n_tri = M.generate(models_dir, d, "x9.obj", 9)
+    def large_class(scene):
+        lay = scene.cull_layout()
+        st = lay["slot_triangle"]
+        return set(int(t) for t in st[(len(lay["bvh"]) - lay["bvh_first_leaf"]) * 8:] if t >= 0)
+    light = large_class(pt.Scene.load_obj(d, "x9.obj", device=-1))
+    assert len(light) == 14 and all(t >= n_tri - 14 for t in light)          # the room: 12 wall triangles and the light's 2
+    # the same scene with an emissive torus material: 2 + 9 * 256 emitters, none of them moved
+    text = open(d + "Tor.mtl").read().replace("newmtl 4\n", "newmtl 4\nKe 0.8 0.6 0.2\n")
+    lines, cur, seen = [], None, False
+    for line in text.split("\n"):
+        tok = line.split()
+        if tok and tok[0] == "newmtl":
+            cur, seen = tok[1], False
+        if tok and tok[0] == "Ke" and cur == "4":
+            if seen:
+                continue                                                     # keep the first Ke line of the material only
+            seen = True
+        lines.append(line)
+    open(d + "Tor.mtl", "w").write("\n".join(lines))
+    many = large_class(pt.Scene.load_obj(d, "x9.obj", device=-1))
+    assert len(many) == 12 and many < light
