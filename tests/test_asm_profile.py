@@ -59,3 +59,23 @@ def test_instrument_and_report(tmp_path):
                        capture_output=True, text=True, check=True).stdout
     assert f"{7 * 2 + 35 * 3 + 7 * 1} instructions executed" in r
     assert "pt_kernels.hip:20" in r
+
+
+def test_pipe_cycle_table():
+    """The weights of the report's "pipe cycles" follow tools/issue_cost.hip (profiles/r02_issue_cost.txt): 2 cycles for the plain
+    fp32 / add / logic forms with vector operands only, 4 with a scalar operand, as DPP and for the rest, 8 for v_rcp / v_rsq."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_profile as A
+    assert A.pipe_cycles("v_fma_f32", "v1, v2, v3, v4") == ("valu", 2.0)
+    assert A.pipe_cycles("v_mul_f32_e32", "v1, 0x40490fdb, v2") == ("valu", 2.0)          # a literal is not a scalar register
+    assert A.pipe_cycles("v_mul_f32_e32", "v1, s7, v2") == ("valu", 4.0)
+    assert A.pipe_cycles("v_fma_f32", "v1, v2, s[4:5], v4")[1] == 4.0
+    assert A.pipe_cycles("v_cndmask_b32_e32", "v1, v2, v3, vcc") == ("valu", 4.0)
+    assert A.pipe_cycles("v_add_u32_dpp", "v1, v2, v1 row_shr:1 row_mask:0xf bank_mask:0xf") == ("valu", 4.0)
+    assert A.pipe_cycles("v_cvt_f32_ubyte0_e32", "v1, v2") == ("valu", 4.0)
+    assert A.pipe_cycles("v_pk_fma_f32", "v[0:1], v[2:3], v[4:5], v[6:7]") == ("valu", 4.0)
+    assert A.pipe_cycles("v_rcp_f32_e32", "v1, v2") == ("valu", 8.0)
+    assert A.pipe_cycles("s_add_u32", "s1, s2, s3") == ("salu", 4.0)
+    assert A.pipe_cycles("s_cbranch_vccnz", ".LBB0_1") == ("salu", 4.0)
+    assert A.pipe_cycles("s_nop", "0")[1] < 1.0
+    assert A.pipe_cycles("ds_write_b32", "v1, v2")[0] == "lds" and A.pipe_cycles("global_load_dwordx4", "v[0:3], v[4:5], off")[0] == "vmem"

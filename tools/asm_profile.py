@@ -169,7 +169,7 @@ def pipe_cycles(op, operands):
             return "valu", 8.0
         if base in SLOW16_VALU:
             return "valu", 16.0
-        scalar_operand = re.search(r"(?<![\w.])(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|exec_lo|exec_hi|m0|ttmp\d+)\b", operands) is not None
+        scalar_operand = re.search(r"(?<![\w.])(s\d+\b|s\[\d+:\d+\]|(?:vcc|vcc_lo|vcc_hi|exec|exec_lo|exec_hi|m0|ttmp\d+)\b)", operands) is not None
         if base in FAST_VALU and not scalar_operand and not op.endswith(("_dpp", "_sdwa")) and "row_" not in operands and "sel:" not in operands:
             return "valu", 2.0
         return "valu", 4.0
