@@ -631,9 +631,13 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         if (emis_only && cl < 32 && !((a.emis_clusters >> cl) & 1u)) continue;   // no emitter in this cluster
         const uint32_t first_tri = ((ConstU)cp)[4], n_tri = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7];
         // (the large class is tested triangle by triangle anyway, and its bounding sphere is the scene's: nothing to gain from it)
-        const bool pc = kind == 0 ? valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q) : valid;
+        // (big scenes have no sphere-tree clusters -- all their small triangles sit under the box tree, pt_scene.cpp --: their
+        // instantiations leave that code out, which spares them its registers)
+        constexpr bool kSphereTrees = !Lds::kPrefilter;
+        if (!kSphereTrees && kind == 0) continue;
+        const bool pc = (kSphereTrees && kind == 0) ? valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q) : valid;
         if (!__any(pc)) continue;
-        if (kind == 0) {
+        if (kSphereTrees && kind == 0) {
             // ---- small triangles: an 8-ary tree of bounding spheres, walked with a wave-wide LIFO of (ray, node) items
             const uint32_t n_levels = ((ConstU)cp)[8];
             const uint32_t top = n_levels - 1;
