@@ -64,6 +64,9 @@ struct SmallQueues { static constexpr int kNodeStack = PT_SMALL_NODES, kPairQueu
 #ifndef PT_BIG_EXACT_AT
 #define PT_BIG_EXACT_AT 64    // big scenes: pre-filtered pairs waiting before an exact round runs (fewer = earlier pruning, emptier rounds)
 #endif
+#ifndef PT_BIG_WAVES
+#define PT_BIG_WAVES (PT_WAVES_PER_SIMD - 2)   // waves per SIMD the big-scene and skybox instantiations are compiled for
+#endif
 struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1025,7 +1028,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 // triangles; CullTables::may_leave_envelope): every segment's origin is then checked.  A compile-time choice because the
 // mere presence of the rare path costs the common scenes 2 % (measured), whether or not it ever runs.
 template <bool SKY, bool BIG, bool STATS, bool ENV>
-__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STATS ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
@@ -1391,7 +1394,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_WAVES_PER_SIMD - 2 : STAT
 
 // Closest hit for caller-supplied rays (the intersection half of Scene::TraceRay, scene.cpp:114-120).
 template <bool BIG>
-__global__ __launch_bounds__(kBlock, BIG ? PT_WAVES_PER_SIMD - 2 : PT_WAVES_PER_SIMD) void trace_rays_kernel(const RenderArgs a, const float *__restrict__ origins,
+__global__ __launch_bounds__(kBlock, BIG ? PT_BIG_WAVES : PT_WAVES_PER_SIMD) void trace_rays_kernel(const RenderArgs a, const float *__restrict__ origins,
                                                                               const float *__restrict__ directions, int n_rays,
                                                                               int32_t *__restrict__ hit_index, float *__restrict__ hit_t) {
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;
