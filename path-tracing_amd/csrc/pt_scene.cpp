@@ -747,9 +747,11 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     // that cannot be bounded at all (degenerate) -- is culled by a barycentric record, wave-uniformly.  SMALL: the rest,
     // under a hierarchy of bounding volumes.
     std::vector<uint8_t> large(T);
+    std::vector<double> own_radius(T);
     for (int i = 0; i < T; ++i) {
         SphereRec tmp;
         const double reff = sphere_of(&i, 1, tmp);
+        own_radius[i] = reff;
         large[i] = !(reff < 0.12 * r_max);
     }
     // A big scene's few emitters (the light of a room) join the large class whatever their size: their records alone then
@@ -759,9 +761,16 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
             const float *m = &s.mat[10 * static_cast<size_t>(s.tri_mat[t])];
             return m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f;
         };
+        // (not tiny ones: the margins of the barycentric test scale with the inverse size of the smallest record, and
+        // every wall would pay for a pinhead of a light)
         int n_emit = 0;
-        for (int i = 0; i < T; ++i) n_emit += emits(i);
-        if (n_emit <= 8)
+        bool sizeable = true;
+        for (int i = 0; i < T; ++i)
+            if (emits(i)) {
+                ++n_emit;
+                sizeable = sizeable && own_radius[i] >= 0.01 * r_max;
+            }
+        if (n_emit <= 8 && sizeable)
             for (int i = 0; i < T; ++i) if (emits(i)) large[i] = 1;
     }
     // connected groups of small triangles (triangles sharing a vertex position): the objects of the scene
