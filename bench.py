@@ -21,16 +21,21 @@ reports it as `configs3_strong` (strong scaling: the frame is fixed, 2160/N rows
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   roofline      the integrator kernel against the roofline that bounds it, vector-ALU issue (the path is
                 neither HBM- nor MFMA-bound): achieved = VALU lane-operations the kernel EXECUTES per second
-                (SQ_INSTS_VALU x 64, counted by rocprofv3 --pmc on this very command in child processes) over the
-                HIP-event kernel time measured live on the launch stream; peak = 78.6 T lane-op/s (1024 SIMDs x 32 lanes
-                x 2.4 GHz, no FMA: parity forbids contraction).  traffic = HBM bytes per launch from FETCH_SIZE and
-                WRITE_SIZE (separate passes).  reference_equivalent_tflops = the REFERENCE's brute-force work
-                (segments x triangles x 31.5 flop) per second -- what the culling hierarchy saves, not a roofline.
+                (SQ_INSTS_VALU x 64, counted by rocprofv3 --pmc child runs of the C++ front end on the same frame) over
+                the HIP-event kernel time measured live on the launch stream; peak = 78.6 T lane-op/s (1024 SIMDs x 32
+                lanes x 2.4 GHz, no FMA: parity forbids contraction).  frac counts issued vector instructions whatever their
+                lane mask; frac_active_lanes = frac x the fraction of lanes that were on; useful_fraction = the part of the
+                executed lane-operations that is the reference's own arithmetic (one exact test + shading per segment).
+                traffic = HBM bytes per launch from FETCH_SIZE and WRITE_SIZE (separate passes).
+                reference_equivalent_tflops = the REFERENCE's brute-force work (segments x triangles x 31.5 flop) per
+                second -- what the culling hierarchy saves, not a roofline.
   cpu_baseline  the CPU oracle (a port of the reference's algorithm) timed on this box's host cores on a bounded sample
   accuracy      the other half of BASELINE's metric: per-channel RMSE against the CPU path
+  cxx_frame     the same frame(s) driven by the C++ host alone (pt_render -GPUS N: pt_frame_*, direct RCCL), as a child process
+  configs1_64spp / adaptive_default / configs4_replica   (N = 1) BASELINE configs[1], the reference-default -ERR 0.001 run
+                with its traced-sample count, and configs[4] (the x64 / x195 replicated scenes) with its own counters
 """
 import argparse
-import ctypes as C
 import csv
 import glob
 import hashlib
@@ -39,6 +44,7 @@ import json
 import os
 import re
 import shutil
+import signal
 import socket
 import subprocess
 import sys
@@ -48,14 +54,19 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 FLOP_PER_TEST = 31.5            # reference's own average over its stage-exit mix
+FLOP_FULL_TEST = 79             # stages A-D of Triangle::Intersect
+FLOP_SHADING = 100              # Material::Process + lobe + Ray::Reflect, per segment
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
 PEAK_VALU_TLANEOPS = 78.6432    # the same without FMA: one operation per lane per clock
 PEAK_HBM_GBS = 8000.0
 BASE_W, BASE_H, SPP, MRR = 1920, 1080, 256, 8
 C3_W, C3_H, C3_SPP = 3840, 2160, 256      # BASELINE configs[3]
 KERNEL_SOURCES = ["pt_kernels.hip", "pt_kernels.hpp", "pt_fastfp.hpp", "pt_scene.cpp", "pt_scene.hpp", "pt_capi.cpp"]
+EXE = os.path.join(ROOT, "path-tracing_amd", "bin", "pt_render")
+MODELS = os.path.join(ROOT, "models") + "/"
 
 
 def host_cores():
@@ -70,10 +81,10 @@ def host_cores():
     return n
 
 
-def timed_instantiation(kernel_name):
-    """integrate_kernel<SKY, BIG, STATS, ENV>: the timed launches are the statistics-free ones (third argument false)."""
+def instantiation(kernel_name):
+    """integrate_kernel<SKY, BIG, STATS, ENV> -> (sky, big, stats, env) as booleans, or None."""
     m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)>", kernel_name.replace(" ", ""))
-    return bool(m) and m.group(3) == "false"
+    return tuple(x == "true" for x in m.groups()) if m else None
 
 
 def kernel_source_sha():
@@ -84,12 +95,29 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def visible_devices():
+    """HIP devices this process may use, WITHOUT touching the HIP runtime (torch.cuda.device_count() would bring the
+    runtime up in this launcher process): the *_VISIBLE_DEVICES lists if set, else the GPU nodes of the KFD topology."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    for p in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split(None, 1) for line in open(p).read().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 # ---------------------------------------------------------------------------------------------------------------------
-# N > 1 without a launcher: start the ranks ourselves (before anything in this process touches the GPU)
+# N > 1 without a launcher: start the ranks ourselves.  This parent never touches the GPU and only ever spawns children.
 # ---------------------------------------------------------------------------------------------------------------------
 def launch_ranks(args, argv):
-    import torch
-    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    have = visible_devices()
     if args.gpus > have and not args.rehearse_on_one_gpu:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible; nothing was run "
                          f"(use --rehearse-on-one-gpu to exercise the {args.gpus}-rank code path on one device)\n")
@@ -111,36 +139,60 @@ def launch_ranks(args, argv):
     return max(abs(rc) for rc in rcs)
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# Hardware counters of the timed kernel: rocprofv3 --pmc over THIS command, in child processes, before the parent
-# touches the GPU.  One counter group per pass, never combined with a trace domain (MI355X_MICROARCH.md "rocprofv3 PMC
-# slots": FETCH_SIZE and WRITE_SIZE do not fit one pass).
-# ---------------------------------------------------------------------------------------------------------------------
-PMC_PASSES = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
-               "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
+def run_group(cmd, timeout, **kw):
+    """subprocess.run in a process group of its own; on timeout the WHOLE group is killed and reaped (rocprofv3's child --
+    the program that holds the GPU -- must not survive its parent and keep the GPU busy under the timed frames)."""
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, **kw)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.communicate()
+        raise
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 
-def pmc_live(args, timeout_s=240):
+# ---------------------------------------------------------------------------------------------------------------------
+# Hardware counters of the timed kernels: rocprofv3 --pmc over the C++ front end rendering the same frame through the same
+# C ABI (pt_render -BENCH_STEPS 1: the statistics-free instantiation, like the timed launches), in child processes, before
+# this process touches the GPU.  One counter group per pass, never combined with a trace domain (MI355X_MICROARCH.md
+# "rocprofv3 PMC slots": FETCH_SIZE and WRITE_SIZE do not fit one pass).
+# ---------------------------------------------------------------------------------------------------------------------
+PMC_SQ = ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
+          "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
+PMC_PASSES_TOR = [PMC_SQ, ["FETCH_SIZE"], ["WRITE_SIZE"]]
+PMC_PASSES_BIG = [PMC_SQ, ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]]
+
+
+def pmc_live(passes, model_dir, model_name, spp, big, deadline):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
+    if not os.path.exists(EXE):
+        return None, "path-tracing_amd/bin/pt_render is not built"
     counters, t0 = {}, time.perf_counter()
     td = tempfile.mkdtemp(prefix="pt_pmc_")
     try:
-        for i, group in enumerate(PMC_PASSES):
-            left = timeout_s - (time.perf_counter() - t0)
-            if left < 20:
+        for i, group in enumerate(passes):
+            left = deadline - time.perf_counter()
+            if left < 10:
                 return None, "time budget of the counter passes exhausted"
             d = os.path.join(td, f"p{i}")
-            cmd = [exe, "--pmc", *group, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
-                   os.path.abspath(__file__), "--pmc-child", "--spp", str(args.spp), "--steps", "1", "--warmup", "1"]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd=td, env=dict(os.environ, TMPDIR=td))
+            cmd = [exe, "--pmc", *group, "-d", d, "-o", "p", "--output-format", "csv", "--", EXE, "--W", str(BASE_W), "--H", str(BASE_H),
+                   "-RPP", str(spp), "-MRR", str(MRR), "-ERR", "-1", "-SEED", "42", "-MODEL_PATH", model_dir, "-MODEL_NAME", model_name,
+                   "-BENCH_STEPS", "1", "-BENCH_WARMUP", "1"]
+            r = run_group(cmd, left, cwd=td, env=dict(os.environ, TMPDIR=td))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 pass {group} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
-            rows = [x for x in csv.DictReader(open(max(files, key=os.path.getmtime))) if "integrate_kernel" in x["Kernel_Name"]]
-            # the timed launches run the instantiation without statistics (third template argument false)
-            rows = [x for x in rows if timed_instantiation(x["Kernel_Name"])]
+            rows = []
+            for x in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                inst = instantiation(x["Kernel_Name"])
+                if inst and not inst[2] and inst[1] == big:      # the statistics-free instantiation of this scene class
+                    rows.append(x)
             launches = len({x["Dispatch_Id"] for x in rows})
             if not launches:
                 return None, f"no integrate_kernel dispatch in pass {group}"
@@ -150,7 +202,7 @@ def pmc_live(args, timeout_s=240):
         return None, f"counter passes failed: {e!r}"
     finally:
         shutil.rmtree(td, ignore_errors=True)
-    return counters, f"rocprofv3 --pmc, {len(PMC_PASSES)} passes over this command in {time.perf_counter() - t0:.0f} s"
+    return counters, f"rocprofv3 --pmc, {len(passes)} passes over pt_render on the same frame in {time.perf_counter() - t0:.0f} s"
 
 
 def pmc_from_file(spp, W, H, kernel_ms):
@@ -165,6 +217,39 @@ def pmc_from_file(spp, W, H, kernel_ms):
             continue
         return j["counters_per_launch"], f"{os.path.relpath(f, ROOT)} (kernel_source_sha {sha}, kernel_ms {j['kernel_ms']:.2f})"
     return None, f"no committed summary for kernel_source_sha {sha} at this configuration"
+
+
+def issue_view(pmc, kms, wave_segments):
+    """The second hardware view: the kernel's time follows the number of instructions its waves issue,
+    vector or scalar alike.  Issue slots = 2 cycles per wave64 vector instruction on a 32-lane SIMD + 1 per scalar / LDS /
+    memory / branch instruction, against 1024 SIMDs x kernel time x 2.4 GHz."""
+    keys = ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD")
+    if not pmc or "SQ_INSTS_VALU" not in pmc or not all(k in pmc for k in keys):
+        return None
+    others = sum(pmc[k] for k in keys)
+    return {"instructions_per_launch": pmc["SQ_INSTS_VALU"] + others,
+            "valu": pmc["SQ_INSTS_VALU"], "salu": pmc["SQ_INSTS_SALU"], "branch": pmc["SQ_INSTS_BRANCH"],
+            "lds": pmc["SQ_INSTS_LDS"], "smem": pmc["SQ_INSTS_SMEM"], "vmem_rd": pmc["SQ_INSTS_VMEM_RD"],
+            "instructions_per_wave_segment": (pmc["SQ_INSTS_VALU"] + others) / wave_segments if wave_segments else None,
+            "issue_slot_fraction": (2.0 * pmc["SQ_INSTS_VALU"] + others) / (1024 * kms * 1e-3 * 2.4e9) if kms > 0 else None,
+            "what": "(2 x vector + 1 x every other instruction) / (1024 SIMDs x kernel time x 2.4 GHz); s_nop / s_waitcnt not counted"}
+
+
+def valu_view(pmc, kms, segments):
+    """achieved / frac / frac_active_lanes / useful_fraction of one kernel from its SQ counters and live kernel time."""
+    if not pmc or "SQ_INSTS_VALU" not in pmc or kms <= 0:
+        return {"achieved": None, "frac": None, "valu_active_lane_fraction": None, "frac_active_lanes": None, "useful_fraction": None}
+    lane_ops = pmc["SQ_INSTS_VALU"] * 64.0
+    achieved = lane_ops / (kms * 1e-3) / 1e12
+    lf = None
+    if pmc.get("SQ_THREAD_CYCLES_VALU"):
+        lf = pmc["SQ_THREAD_CYCLES_VALU"] / lane_ops
+        lf = lf if lf <= 1.0 else None
+    frac = achieved / PEAK_VALU_TLANEOPS
+    return {"achieved": achieved, "frac": frac, "valu_active_lane_fraction": lf,
+            "frac_active_lanes": frac * lf if lf is not None else None,
+            # the reference's own arithmetic in what was executed: one full Triangle::Intersect + the shading of every segment
+            "useful_fraction": segments * (FLOP_FULL_TEST + FLOP_SHADING) / lane_ops if segments else None}
 
 
 def cpu_baseline(models, target_seconds, pt, scene):
@@ -194,13 +279,15 @@ def cpu_baseline(models, target_seconds, pt, scene):
 
     v_all, what_all, (r0, r1, spp, cpu_acc) = timed(cores, target_seconds * 0.65)
     v_4, what_4, _ = timed(min(4, cores), target_seconds * 0.35)
-    # accuracy: the same rows x passes through the C ABI on the GPU, then the reference's resolve on both
-    gs, gs2, gc, _ = scene.render_host(BASE_W, BASE_H, spp, MRR, rows=(r0, r1))
+    # accuracy: the same rows x passes through the C ABI on the GPU -- WITHOUT statistics, i.e. the instantiation the timed
+    # launches run (emitter-first last segment and all) -- then the reference's resolve on both
+    gs, gs2, gc, _ = scene.render_host(BASE_W, BASE_H, spp, MRR, rows=(r0, r1), want_stats=False)
     g_rgb, _ = pt.resolve_float(BASE_W, r1 - r0, gs, gs2, gc)
     c_rgb, _ = pt.resolve_float(BASE_W, r1 - r0, *cpu_acc)
     d = g_rgb.astype(np.float64) - c_rgb.astype(np.float64)
     g_bgr, c_bgr = pt.quantize(g_rgb, gc), pt.quantize(c_rgb, cpu_acc[2])
     accuracy = {"vs": "cpu_baseline sample (same rows, passes, seed; counter RNG on both sides)",
+                "gpu_instantiation": "integrate_kernel<false,false,false,false> (statistics-free: the one the timed launches run)",
                 "rmse_rgb_float_image": [float(np.sqrt(np.mean(d[..., k] ** 2))) for k in range(3)],
                 "max_abs_diff_float_image": float(np.abs(d).max()),
                 "bmp_bytes_differing": int(np.count_nonzero(g_bgr != c_bgr)),
@@ -239,6 +326,29 @@ def reference_stream_accuracy(models, pt, scene):
             "tolerance": R.TOLERANCE, "within_tolerance": ok}
 
 
+def cxx_frame_leg(n_bands, W, H, spp, steps, warmup, rehearse, error=-1.0, model_dir=MODELS, model_name="Tor.obj"):
+    """The frame driven by the C++ host program alone (tools/pt_render.cpp over pt_frame_*: per-device sessions on row bands,
+    every slice enqueued on all devices before any wait, ONE direct RCCL group of sends / receives to the root) as a child
+    process: the same W x H x spp frame and the same step as the torch-driven legs."""
+    if not os.path.exists(EXE):
+        return {"error": "path-tracing_amd/bin/pt_render is not built"}
+    cmd = [EXE, "--W", str(W), "--H", str(H), "-RPP", str(spp), "-MRR", str(MRR), "-ERR", str(error), "-SEED", "42", "-MODEL_PATH", model_dir,
+           "-MODEL_NAME", model_name, "-GPUS", str(n_bands), "-BENCH_STEPS", str(steps), "-BENCH_WARMUP", str(warmup)]
+    if rehearse:
+        cmd += ["-REHEARSE", "1"]
+    try:
+        r = run_group(cmd, 300)
+    except subprocess.TimeoutExpired:
+        return {"error": "pt_render timed out"}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"pt_render rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    j = json.loads(lines[-1])
+    j["what"] = ("pt_render -GPUS N -BENCH_STEPS k (C++ host, pt_frame_*; RCCL send/recv group for N > 1" +
+                 ("; REHEARSAL: device copies, bands share devices" if rehearse else "") + "), a child process")
+    return j
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,15 +357,15 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of the frame (BASELINE configs: 64 / 256 / 1024)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget; 0 skips it")
     ap.add_argument("--pmc", choices=["live", "file", "off"], default="live",
-                    help="hardware counters of the timed kernel: collected now with rocprofv3 in child processes (N = 1), read "
+                    help="hardware counters of the timed kernels: collected now with rocprofv3 in child processes (N = 1), read "
                          "from a committed summary of the same kernel source, or omitted")
     ap.add_argument("--no-configs3", action="store_true", help="skip the 3840x2160 x 256 spp strong-scaling leg")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip configs1_64spp / adaptive_default / configs4_replica / cxx_frame")
     ap.add_argument("--save-pmc", default="", help="write the live counters as a summary `--pmc file` can read later (profiles/rNN_pmc_hbm.json)")
     ap.add_argument("--write-bmp", default="", help="resolve rank 0's gathered frame and write it here")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all render on device 0 and gather over gloo (host copies): exercises the multi-rank "
                          "code path on a one-GPU box; the number it prints is NOT a scaling result")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps: launches only
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -265,10 +375,23 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    extra = world == 1 and not args.no_extra_legs
 
-    pmc, pmc_source = None, "not collected"
-    if world == 1 and args.pmc == "live" and not args.pmc_child:
-        pmc, pmc_source = pmc_live(args)      # child processes; this process has not touched the GPU yet
+    # the replicated scenes of BASELINE configs[4] (generated: 64 and 195 torus instances in the room)
+    replica_dir, replicas = None, []
+    if extra:
+        import make_replicated_scene as M
+        replica_dir = tempfile.mkdtemp(prefix="pt_replica_")
+        for inst in (64, 195):
+            name = f"TorX{inst}.obj"
+            replicas.append((inst, name, M.generate(os.path.join(ROOT, "models"), replica_dir + "/", name, inst)))
+
+    pmc, pmc_source, pmc_big, pmc_big_source = None, "not collected", None, "not collected"
+    if world == 1 and args.pmc == "live":      # child processes; this process has not touched the GPU yet
+        deadline = time.perf_counter() + 120
+        pmc, pmc_source = pmc_live(PMC_PASSES_TOR, MODELS, "Tor.obj", args.spp, False, deadline)
+        if extra:
+            pmc_big, pmc_big_source = pmc_live(PMC_PASSES_BIG, replica_dir + "/", replicas[0][1], SPP, True, deadline)
 
     import numpy as np
     import torch
@@ -293,12 +416,11 @@ def main():
         dist.all_reduce(one)                  # every rank is really in the communicator
         rccl_ranks_seen = int(one.item())
 
-    models = os.path.join(ROOT, "models") + "/"
-    scene = pt.Scene.load_obj(models, "Tor.obj", device=local)
+    scene = pt.Scene.load_obj(MODELS, "Tor.obj", device=local)
     n_tri = scene.counts()[0]
     stream = torch.cuda.current_stream(dev)
 
-    def run_frames(W, H, spp, steps, warmup):
+    def run_frames(sc, W, H, spp, steps, warmup, error=-1.0):
         """Renders `warmup` untimed and `steps` timed frames of a W x H x spp image cut into `world` row bands; returns
         wall seconds (max over ranks), per-step kernel times of this rank, the frame's counters and the gathered frame."""
         r0, r1 = bands.band_rows(H, world, rank)
@@ -311,7 +433,7 @@ def main():
         band_bufs = [torch.zeros(bands.band_floats(W, rows), dtype=torch.float32, device=dev) for _ in range(n_band)]
         recv_bufs = [None] * n_band     # rank 0: receive buffers, one set per band buffer
         gathered, in_flight, frame_no, events = [None], [None], [0], []
-        params = pt.RenderParams(W, H, r0, r1, 0, spp, MRR, 1e-4, -1.0, 42)
+        params = pt.RenderParams(W, H, r0, r1, 0, spp, MRR, 1e-4, error, 42)
 
         def finish_gather():
             if in_flight[0] is not None:
@@ -332,11 +454,11 @@ def main():
                 # diagnostic counters, as a caller that only wants the frame does), bracketed by HIP events on the launch stream.
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=False)
+                sc.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=False)
                 e1.record(stream)
                 events.append((e0, e1))
             else:
-                st = scene.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=True)
+                st = sc.render_device(params, p_sum, p_sum2, p_cnt, stream=stream.cuda_stream, want_stats=True)
             if world > 1:   # the frame's one collective (RCCL; gloo on host copies when rehearsing)
                 finish_gather()         # at most one gather in flight; it read the OTHER band buffer
                 send = band.cpu() if args.rehearse_on_one_gpu else band
@@ -368,21 +490,79 @@ def main():
         frame = gathered[0] if world > 1 else [band_bufs[0]]
         return elapsed, kernel_ms, frame_stats, frame, rows
 
-    if args.pmc_child:
-        run_frames(BASE_W, BASE_H, args.spp, args.steps, args.warmup)
-        return
+    def leg(sc, W, H, spp, steps, workload, error=-1.0):
+        e, kms, st, _, _ = run_frames(sc, W, H, spp, steps, 1, error)
+        return {"workload": workload, "value": W * H * spp * steps / e / 1e6, "unit": "Msamples/s", "steps": steps,
+                "ms_per_step": e / steps * 1e3, "kernel_ms": sum(kms) / max(len(kms), 1)}, st
 
     W, H = bands.frame_for(world)
-    elapsed, kernel_ms, frame_stats, frame, rows = run_frames(W, H, args.spp, args.steps, args.warmup)
+    elapsed, kernel_ms, frame_stats, frame, rows = run_frames(scene, W, H, args.spp, args.steps, args.warmup)
     c3 = None
     if not args.no_configs3:
         c3_steps = max(1, min(args.steps, 5))
-        c3_elapsed, c3_kms, c3_stats, _, c3_rows = run_frames(C3_W, C3_H, C3_SPP, c3_steps, 1)
+        c3_elapsed, c3_kms, c3_stats, _, c3_rows = run_frames(scene, C3_W, C3_H, C3_SPP, c3_steps, 1)
         c3 = {"workload": f"BASELINE configs[3]: Tor.obj {C3_W}x{C3_H} x {C3_SPP} spp, -MRR {MRR}, -ERR -1, {world} row band(s) of "
                           f"{c3_rows} rows" + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
               "value": C3_W * C3_H * C3_SPP * c3_steps / c3_elapsed / 1e6, "unit": "Msamples/s", "scaling": "strong",
               "steps": c3_steps, "ms_per_step": c3_elapsed / c3_steps * 1e3,
               "kernel_ms_rank0": sum(c3_kms) / max(len(c3_kms), 1)}
+
+    legs = {}
+    if extra:
+        # BASELINE configs[1] on identical work from round to round (the headline moved from 64 to 256 spp in round 2)
+        legs["configs1_64spp"], _ = leg(scene, BASE_W, BASE_H, 64, 5, f"BASELINE configs[1]: Tor.obj {BASE_W}x{BASE_H} x 64 spp, -MRR {MRR}, -ERR -1")
+        # SURVEY 8(d) "run every config twice": the reference's default, adaptive sampling on (-ERR 0.001, main.cpp:118-125)
+        ad, ad_st = leg(scene, BASE_W, BASE_H, SPP, 5, f"Tor.obj {BASE_W}x{BASE_H} x {SPP} spp, -MRR {MRR}, -ERR 0.001 (reference default: "
+                        "adaptive sampling skips low-variance pixels on 3 of 4 passes after pass 10)", error=0.001)
+        ad["nominal_samples"] = BASE_W * BASE_H * SPP
+        ad["samples_traced"] = int(ad_st["samples_traced"])
+        ad["value_nominal"] = ad["value"]
+        ad["value_traced"] = ad["value"] * ad["samples_traced"] / ad["nominal_samples"]
+        ad["what"] = "value = nominal W*H*spp per second (the reference's own accounting); value_traced counts only samples really traced"
+        legs["adaptive_default"] = ad
+        # BASELINE configs[4]: the replicated scenes, 1080p x 256 spp, driver-timed
+        rep = {}
+        for inst, name, tri in replicas:
+            big_scene = pt.Scene.load_obj(replica_dir + "/", name, device=local)
+            steps = 5 if inst == 64 else 3
+            r, st = leg(big_scene, BASE_W, BASE_H, SPP, steps, f"BASELINE configs[4]: Tor.obj torus x {inst} in the room = {tri} triangles, "
+                        f"{BASE_W}x{BASE_H} x {SPP} spp, -MRR {MRR}, -ERR -1")
+            r["triangles"] = tri
+            wseg = float(st["wave_segments"]) or None
+            r["node_rounds_per_wave_segment"] = st["wave_node_rounds"] / wseg if wseg else None
+            r["exact_rounds_per_wave_segment"] = st["wave_exact_iterations"] / wseg if wseg else None
+            r["exact_tests_per_segment"] = st["exact_tests"] / st["segments"] if st["segments"] else None
+            r["host"] = big_scene.timings()
+            if inst == 64:
+                v = valu_view(pmc_big, r["kernel_ms"], float(st["segments"]))
+                rf = {"bound": "valu_issue", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s", **v,
+                      "kernel": "pt::integrate_kernel<false,true,false,false>", "kernel_ms": r["kernel_ms"],
+                      "issue": issue_view(pmc_big, r["kernel_ms"], wseg), "counters_source": pmc_big_source,
+                      "l1_hit_rate": (1 - pmc_big["TCP_TCC_READ_REQ_sum"] / pmc_big["TCP_TOTAL_CACHE_ACCESSES_sum"])
+                      if pmc_big and pmc_big.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+                      "l1_accesses_per_cu_cycle": (pmc_big["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / (pmc_big["GRBM_GUI_ACTIVE"] / 8))
+                      if pmc_big and pmc_big.get("TCP_TOTAL_CACHE_ACCESSES_sum") and pmc_big.get("GRBM_GUI_ACTIVE") else None}
+                r["roofline"] = rf
+            rep[f"x{inst}"] = r
+            big_scene.close()
+        legs["configs4_replica"] = rep
+
+    # the C++ host alone on the same frame(s): N = 1 must agree with `value`; for N > 1 it is the direct-RCCL frame path
+    cxx = None
+    if not args.no_extra_legs:
+        if world > 1:
+            store = dist.distributed_c10d._get_default_store()
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            if rank == 0:       # the other ranks wait on the store (on the CPU): their GPUs stay idle for the child
+                cxx = {"weak": cxx_frame_leg(world, W, H, args.spp, max(1, min(args.steps, 10)), 1, args.rehearse_on_one_gpu)}
+                if not args.no_configs3:
+                    cxx["configs3_strong"] = cxx_frame_leg(world, C3_W, C3_H, C3_SPP, max(1, min(args.steps, 5)), 1, args.rehearse_on_one_gpu)
+                store.set("cxx_frame_done", "1")
+            else:
+                store.wait(["cxx_frame_done"])
+        else:
+            cxx = {"weak": cxx_frame_leg(1, W, H, args.spp, max(1, min(args.steps, 10)), 1, False)}
 
     if rank == 0:
         k = max(args.steps, 1)
@@ -398,41 +578,22 @@ def main():
             pmc, pmc_source = pmc_from_file(args.spp, W, H, kms)
             if pmc is None:
                 pmc_source = f"{why}; {pmc_source}"
-        lane_ops = traffic = lane_frac = util = None
-        if pmc:
-            if "SQ_INSTS_VALU" in pmc:
-                lane_ops = pmc["SQ_INSTS_VALU"] * 64.0
-                if pmc.get("SQ_THREAD_CYCLES_VALU"):
-                    lf = pmc["SQ_THREAD_CYCLES_VALU"] / lane_ops
-                    lane_frac = lf if lf <= 1.0 else None
-            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                # KiB -> bytes.  The guide's x2 on FETCH_SIZE is for wide streaming reads; this kernel's reads are 4-byte
-                # strided accumulator loads, calibrated 0.76-1.0 : 1 on their known byte count
-                traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        traffic = None
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # KiB -> bytes.  The guide's x2 on FETCH_SIZE is for wide streaming reads; this kernel's reads are 4-byte
+            # strided accumulator loads, calibrated 0.76-1.0 : 1 on their known byte count
+            traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         if args.save_pmc and pmc and pmc_source.startswith("rocprofv3"):
             json.dump({"kernel": "pt::integrate_kernel<false,false,false,false>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
                        "kernel_source_sha": kernel_source_sha(), "kernel_ms": kms, "counters_per_launch": pmc,
                        "collected_by": "bench.py --save-pmc: " + pmc_source,
                        "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes; SQ_INSTS_VALU counts wave-instructions"},
                       open(args.save_pmc, "w"), indent=1)
-        achieved = lane_ops / (kms * 1e-3) / 1e12 if lane_ops and kms > 0 else None
-        # The second hardware view: the kernel's time follows the number of instructions its waves issue,
-        # vector or scalar alike (calibration builds with 200 extra instructions per wave-segment).  Issue slots = 2 cycles per
-        # wave64 vector instruction on a 32-lane SIMD + 1 per scalar / LDS / memory / branch instruction, against
-        # 1024 SIMDs x kernel time x 2.4 GHz.
-        issue = None
-        if pmc and all(k in pmc for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD")):
-            others = sum(pmc[k] for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD"))
-            wseg = float(frame_stats.get("wave_segments", 0)) or None
-            issue = {"instructions_per_launch": pmc["SQ_INSTS_VALU"] + others,
-                     "valu": pmc["SQ_INSTS_VALU"], "salu": pmc["SQ_INSTS_SALU"], "branch": pmc["SQ_INSTS_BRANCH"],
-                     "lds": pmc["SQ_INSTS_LDS"], "smem": pmc["SQ_INSTS_SMEM"], "vmem_rd": pmc["SQ_INSTS_VMEM_RD"],
-                     "instructions_per_wave_segment": (pmc["SQ_INSTS_VALU"] + others) / wseg if wseg else None,
-                     "issue_slot_fraction": (2.0 * pmc["SQ_INSTS_VALU"] + others) / (1024 * kms * 1e-3 * 2.4e9) if kms > 0 else None,
-                     "what": "(2 x vector + 1 x every other instruction) / (1024 SIMDs x kernel time x 2.4 GHz); s_nop / s_waitcnt not counted"}
+        v = valu_view(pmc, kms, seg)
+        wseg = float(frame_stats.get("wave_segments", 0)) or None
         ref_eq = seg * n_tri * FLOP_PER_TEST / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out = {
-            "metric": "Msamples/sec (WxHxspp/wall) on Tor.obj 1080p",
+            "metric": f"Msamples/sec (WxHxspp/wall) on Tor.obj 1080p x {args.spp} spp",
             "value": samples_per_step * k / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -445,16 +606,20 @@ def main():
                                    f"{world} row band(s) of {rows} rows" + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
                        "width": W, "height": H, "spp": args.spp, "max_ray_reflections": MRR, "triangles": n_tri,
                        "parallelism": f"rowband{world}"},
-            "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
-                         "frac": achieved / PEAK_VALU_TLANEOPS if achieved is not None else None,
+            "roofline": {"bound": "valu_issue", "achieved": v["achieved"], "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
+                         "frac": v["frac"],
                          "traffic": traffic,
                          "kernel": "pt::integrate_kernel<false,false,false,false>", "kernel_ms": kms,
                          "what": "achieved = executed VALU lane-operations (SQ_INSTS_VALU x 64) / live HIP-event kernel time; "
-                                 "peak = 1024 SIMDs x 32 lanes x 2.4 GHz (no FMA: parity forbids contraction)",
+                                 "peak = 1024 SIMDs x 32 lanes x 2.4 GHz (no FMA: parity forbids contraction); frac counts issued "
+                                 "instructions whatever their lane mask, frac_active_lanes = frac x active-lane fraction, useful_fraction = "
+                                 f"segments x ({FLOP_FULL_TEST} + {FLOP_SHADING}) flop of the reference's own arithmetic / executed lane-operations",
                          "counters_source": pmc_source, "kernel_source_sha": kernel_source_sha(),
                          "valu_instructions_per_launch": pmc.get("SQ_INSTS_VALU") if pmc else None,
-                         "valu_active_lane_fraction": lane_frac,
-                         "issue": issue,
+                         "valu_active_lane_fraction": v["valu_active_lane_fraction"],
+                         "frac_active_lanes": v["frac_active_lanes"],
+                         "useful_fraction": v["useful_fraction"],
+                         "issue": issue_view(pmc, kms, wseg),
                          "segments_per_launch": seg, "exact_tests_per_segment": frame_stats["exact_tests"] / seg if seg else None,
                          "reference_equivalent_tflops": ref_eq, "reference_equivalent_over_fp32_peak": ref_eq / PEAK_FP32_VALU_TFLOPS,
                          "flop_per_test": FLOP_PER_TEST,
@@ -470,6 +635,14 @@ def main():
             out["rccl_ranks_seen"] = rccl_ranks_seen
         if c3 is not None:
             out["configs3_strong"] = c3
+        out.update(legs)
+        if cxx is not None:
+            w = cxx["weak"]
+            if "value" in w:
+                w["over_torch_leg"] = w["value"] / out["value"]
+            if "configs3_strong" in cxx and c3 is not None and "value" in cxx["configs3_strong"]:
+                cxx["configs3_strong"]["over_torch_leg"] = cxx["configs3_strong"]["value"] / c3["value"]
+            out["cxx_frame"] = cxx
         if world == 1:
             # the host-buffer boundary (pt_render_host): same frame, accumulators staged over PCIe both ways; not `value`
             acc = (np.zeros((npx, 3), np.float32), np.zeros((npx, 3), np.float32), np.zeros(npx, np.int32))
@@ -479,13 +652,14 @@ def main():
             th = time.perf_counter() - th
             out["pcie_inclusive"] = {"value": samples_per_step / th / 1e6, "unit": "Msamples/s", "ms_per_step": th * 1e3,
                                      "what": "pt_render_host: 116 MB of accumulators host->device and back around the same frame"}
-        exe = os.path.join(ROOT, "path-tracing_amd", "bin", "pt_render")
-        if world == 1 and os.path.exists(exe):
-            # end to end: the stand-alone front end from process start to the BMP on disk -- HIP start-up,
-            # OBJ/MTL load, table build, render, resolve (powf), BMP write.  A child process.
+        if world == 1 and os.path.exists(EXE):
+            # end to end: the stand-alone front end from process start to the BMP on disk -- exec + dynamic
+            # linking, OBJ/MTL parse, HIP start-up, table upload, hierarchy build, render, read-back, resolve (powf), BMP write,
+            # exit.  A child process; -T0_NS lets it report the time before main().
             with tempfile.TemporaryDirectory() as td:
-                cmd = [exe, "--W", str(W), "--H", str(H), "-RPP", str(args.spp), "-MRR", str(MRR), "-ERR", "-1", "-UPDATE", "0",
-                       "-QUIET", "1", "-SEED", "42", "-MODEL_PATH", models, "-OUT", os.path.join(td, "frame.bmp"), "-TIMING", "1"]
+                cmd = [EXE, "--W", str(W), "--H", str(H), "-RPP", str(args.spp), "-MRR", str(MRR), "-ERR", "-1", "-UPDATE", "0",
+                       "-QUIET", "1", "-SEED", "42", "-MODEL_PATH", MODELS, "-OUT", os.path.join(td, "frame.bmp"), "-TIMING", "1",
+                       "-FASTEXIT", "1", "-T0_NS", str(time.time_ns())]
                 te = time.perf_counter()
                 r = subprocess.run(cmd, cwd=td, capture_output=True, text=True)
                 te = time.perf_counter() - te
@@ -494,12 +668,16 @@ def main():
                 for line in r.stderr.splitlines():
                     if line.startswith("{") and "hip_startup_s" in line:
                         phases = json.loads(line)
+            unexplained = None
+            if phases:
+                unexplained = te - phases["pre_main_s"] - phases["main_s"]
             out["end_to_end"] = {"value": samples_per_step / te / 1e6 if ok else None, "unit": "Msamples/s", "seconds": te,
-                                 "phases": phases,
-                                 "what": "pt_render (C++ front end) as a child process: process start -> BMP on disk"}
+                                 "phases": phases, "exit_and_wait_s": unexplained,
+                                 "what": "pt_render (C++ front end) as a child process: process start -> BMP on disk -> exit; "
+                                         "seconds = pre_main_s + main_s + exit_and_wait_s"}
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"], out["accuracy"] = cpu_baseline(models, args.cpu_seconds, pt, scene)
-            out["accuracy"]["vs_reference_stream"] = reference_stream_accuracy(models, pt, scene)
+            out["cpu_baseline"], out["accuracy"] = cpu_baseline(MODELS, args.cpu_seconds, pt, scene)
+            out["accuracy"]["vs_reference_stream"] = reference_stream_accuracy(MODELS, pt, scene)
         if args.write_bmp:
             parts = [t.cpu().numpy() for t in frame]
             s, s2, c = bands.assemble(parts, W, H, world)
@@ -507,6 +685,8 @@ def main():
             pt.write_bmp(args.write_bmp, bgr)
             out["config"]["dispersion_max_min_avg"] = [float(d) for d in disp]
         print(json.dumps(out), flush=True)
+    if replica_dir:
+        shutil.rmtree(replica_dir, ignore_errors=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,9 +25,13 @@
  * A render call ADDS passes [pass_begin, pass_begin+pass_count) to the buffers it is given, so a frame can be
  * rendered in slices (previews, time limits: main.cpp:111-114,141-158) and an image in row bands (multi-GPU).
  * There is no CPU fallback: without a usable HIP device the render entry points fail with PT_ERR_NO_DEVICE.
- * Threads and streams: a pt_scene may be rendered from several host threads and on several streams; the library
- * orders the launches of ONE scene on the device (they share its scheduler state), launches of different scenes are
- * independent.  pt_scene_set_skybox_bmp and pt_scene_destroy must not race with a render of the same scene.
+ * Threads and streams: a pt_scene may be rendered from several host threads and on several streams.  Launches made through
+ * pt_render_device / pt_render_host share the scene's scheduler state and are ordered on the device; every pt_session has
+ * its own, so sessions of ONE scene (row bands of an image) run side by side, and launches of different scenes are
+ * independent anyway.  Calls on one pt_session / pt_frame are serialised by the caller.  pt_scene_set_skybox_bmp and
+ * pt_scene_destroy must not race with a render of the same scene.
+ * Several GPUs: pt_frame_* (below) renders one image on the devices of one node from one host program -- row bands, one RCCL
+ * group of sends / receives to the root -- the counterpart of the reference's `omp parallel for` over rows, main.cpp:115,132,141.
  */
 #ifndef PT_HIP_H
 #define PT_HIP_H
@@ -39,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -112,6 +116,11 @@ int pt_scene_load_obj(const char *model_dir, const char *model_name, int device,
 int pt_scene_create(const float *triangles, const int32_t *triangle_material, int32_t n_triangles,
                     const float *materials, int32_t n_materials, int device, pt_scene **out);
 
+/* The same scene on another device (or host-only, device < 0): the parsed model, its tables and the culling hierarchies built
+ * so far are SHARED with `scene` (reference-counted; either may be destroyed first), only the device copies are new.  A skybox
+ * set before the call is inherited. */
+int pt_scene_clone_to_device(const pt_scene *scene, int device, pt_scene **out);
+
 /* -SKYBOX (config.h:26, scene.cpp:20-22): load a 24-bit BMP with bitmap_image::load_bitmap's checks
  * (bitmap_image.hpp:1508-1603) as the scene's skybox; rays that hit nothing then add its bilinear sample to the
  * accumulators (scene.cpp:126-154).  NULL or "" removes the skybox.  Not to be called while a render is in flight. */
@@ -149,6 +158,45 @@ int pt_session_wait(pt_session *session);                                       
 int pt_session_read(pt_session *session, float *sum, float *sum2, int32_t *count);   /* waits, then copies out */
 int pt_session_clear(pt_session *session);
 void pt_session_destroy(pt_session *session);
+
+/* ---- one image on several GPUs --------------------------------------------------------------------- */
+
+/* The reference splits the image's rows over its OpenMP threads inside the pass loop (main.cpp:115,132,141); a pt_frame splits
+ * them over DEVICES: n_bands contiguous row bands (band b on devices[b]; they differ by at most one row), every band a
+ * pt_session on its device.  pt_frame_render enqueues a pass slice on every device before it waits for anything;
+ * pt_frame_gather brings the bands' accumulators (28 bytes per pixel) to the root device devices[0] with ONE RCCL group of
+ * ncclSend / ncclRecv pairs, received straight into the root's full-frame planes (the root's own band renders into those
+ * planes directly and is never copied); pt_frame_read copies the full frame to the host, where the unmodified pt_resolve
+ * runs.  The result is bit-identical to the one-device frame for any n_bands (the RNG is keyed by the global pixel index).
+ * `scene` is only read (any device, or host-only): the frame makes its own per-device copies, which share the parsed
+ * model and the hierarchy.
+ * flags: PT_FRAME_REHEARSE -- devices[] may name a device several times (the N-band code path on a one-GPU box); the
+ *   gather is then NOT a collective but the same transfers as device-to-device copies (pt_frame_info: transport).
+ *   Without it, two bands on one device are refused: nothing falls back silently.
+ *   PT_FRAME_SELF_COLLECTIVE -- test aid: ONE band, rendered into a band buffer of its own and gathered to the frame planes
+ *   of the same device by an RCCL send / receive to self, so that the collective path can be exercised on one device.
+ * librccl.so is loaded on first use, by a frame with the RCCL transport (or pt_rccl_available); a one-band frame never loads it. */
+typedef struct pt_frame pt_frame;
+#define PT_FRAME_REHEARSE 1u
+#define PT_FRAME_SELF_COLLECTIVE 2u
+#define PT_FRAME_TRANSPORT_NONE 0            /* one band: it renders into the frame planes */
+#define PT_FRAME_TRANSPORT_RCCL 1            /* one group of ncclSend / ncclRecv */
+#define PT_FRAME_TRANSPORT_DEVICE_COPIES 2   /* rehearsal: hipMemcpyAsync / hipMemcpyPeerAsync */
+int pt_frame_create(const pt_scene *scene, const int32_t *devices, int32_t n_bands, int32_t width, int32_t height,
+                    uint32_t flags, pt_frame **out);                                  /* accumulators start at zero */
+/* band_rows: 2 per band, [begin, end); band_device: 1 per band; any pointer may be NULL */
+int pt_frame_info(const pt_frame *frame, int32_t *n_bands, int32_t *band_rows, int32_t *band_device, int32_t *transport);
+/* params->width / height must equal the frame's, row_begin / row_end must be 0 / height (the frame owns the split);
+ * pass_begin / pass_count select the slice.  Returns without waiting unless stats != NULL (then: sums over the bands,
+ * kernel_ms = the slowest band's). */
+int pt_frame_render(pt_frame *frame, const pt_render_params *params, pt_render_stats *stats);
+int pt_frame_gather(pt_frame *frame);   /* enqueue the one collective of the frame; asynchronous */
+int pt_frame_wait(pt_frame *frame);     /* until everything enqueued so far -- kernels and gather -- is done */
+int pt_frame_read(pt_frame *frame, float *sum, float *sum2, int32_t *count);   /* gathers if a band changed since the last gather, waits, copies out */
+int pt_frame_clear(pt_frame *frame);
+void pt_frame_destroy(pt_frame *frame);
+/* Can RCCL be loaded and does it export what the gather calls?  version = ncclGetVersion's.  Needs no GPU. */
+int pt_rccl_available(int32_t *version);
 
 /* Closest hit for caller-supplied rays: the triangle loop of Scene::TraceRay (scene.cpp:114-120) on the GPU.
  * origins/directions: 3 floats per ray (HOST buffers).  hit_index[i] = index of the accepted triangle with the
@@ -208,6 +256,15 @@ int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clu
  * scene, 64 bytes per node (path-tracing_amd/csrc/pt_scene.hpp: BvhNode).  Pass NULL to skip either.
  * In pt_scene_cull_tables the cluster fields first_tri / n_tri are slot ranges. */
 int pt_scene_cull_layout(pt_scene *scene, float eps, int32_t *counts, int32_t *slot_triangle, void *bvh_nodes);
+
+/* The kernels' tables pack indices into bit fields: (ray, slot) work items hold a slot in 24 bits, a box-tree node its child
+ * base in 21, a sphere tree has at most 8 levels.  A hierarchy beyond that is refused with PT_ERR_UNSUPPORTED when it is
+ * built (first render with an eps, pt_scene_cull_tables / _layout), never truncated; this is the check itself, for counts. */
+int pt_table_limits_check(uint64_t n_slots, uint64_t n_bvh_nodes, int32_t n_levels);
+
+/* Host seconds spent on this scene's model so far: seconds[0] = parsing + per-triangle tables (pt_scene_load_obj /
+ * pt_scene_create), seconds[1] = building culling hierarchies (one per eps, shared by all per-device copies). */
+int pt_scene_timings(const pt_scene *scene, double *seconds);
 
 /* Page-locked host memory for accumulator buffers: transfers to and from it run at PCIe speed without the runtime's
  * staging copies (a first pageable transfer in a fresh process cost 0.1 s for a 1080p band here).  Optional: every entry

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "lib", "libpt_hip
 PT_OK = 0
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT_ERR_PARSE", 4: "PT_ERR_NO_DEVICE",
                 5: "PT_ERR_HIP", 6: "PT_ERR_OUT_OF_MEMORY", 7: "PT_ERR_UNSUPPORTED"}
-PT_ABI_VERSION = 2
+PT_ABI_VERSION = 3
 RNG_COUNTER, RNG_REFERENCE_STREAM = 0, 1
 # test-only builds of the same ABI (csrc/Makefile): never loaded by the product path
 VERIFY_LIB_PATH = os.path.join(_HERE, "lib", "libpt_verify.so")
@@ -32,7 +32,12 @@ ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_sc
                "pt_session_create", "pt_session_render", "pt_session_wait", "pt_session_read", "pt_session_clear", "pt_session_destroy",
                "pt_scene_cull_tables", "pt_scene_cull_layout", "pt_scene_set_skybox_bmp", "pt_resolve", "pt_resolve_float",
                "pt_post_filter_host", "pt_quantize",
-               "pt_write_bmp", "pt_host_alloc", "pt_host_free", "pt_abi_version", "pt_device_count", "pt_last_error"]
+               "pt_write_bmp", "pt_host_alloc", "pt_host_free", "pt_abi_version", "pt_device_count", "pt_last_error",
+               "pt_scene_clone_to_device", "pt_scene_timings", "pt_table_limits_check", "pt_rccl_available",
+               "pt_frame_create", "pt_frame_info", "pt_frame_render", "pt_frame_gather", "pt_frame_wait", "pt_frame_read",
+               "pt_frame_clear", "pt_frame_destroy"]
+FRAME_REHEARSE, FRAME_SELF_COLLECTIVE = 1, 2
+TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "device_copies"}
 
 
 class PtError(RuntimeError):
@@ -130,6 +135,19 @@ def load_library(path):
     L.pt_host_alloc.argtypes = [C.c_size_t]
     L.pt_host_free.argtypes = [C.c_void_p]
     L.pt_host_free.restype = None
+    L.pt_scene_clone_to_device.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.pt_scene_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    L.pt_table_limits_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int32]
+    L.pt_rccl_available.argtypes = [ip]
+    L.pt_frame_create.argtypes = [vp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(vp)]
+    L.pt_frame_info.argtypes = [vp, ip, ip, ip, ip]
+    L.pt_frame_render.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(RenderStats)]
+    L.pt_frame_gather.argtypes = [vp]
+    L.pt_frame_wait.argtypes = [vp]
+    L.pt_frame_read.argtypes = [vp, fp, fp, ip]
+    L.pt_frame_clear.argtypes = [vp]
+    L.pt_frame_destroy.argtypes = [vp]
+    L.pt_frame_destroy.restype = None
     if hasattr(L, "pt_test_set_mutation"):
         L.pt_test_set_mutation.argtypes = [C.c_char_p, C.c_double]
     return L
@@ -213,6 +231,17 @@ class Scene:
         st = RenderStats()
         _check(self._L.pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None), self._L)
         return s, s2, c, st.as_dict()
+
+    def clone_to_device(self, device):
+        """The same scene on another device; host side (parsed model, hierarchies) shared."""
+        h = C.c_void_p()
+        _check(self._L.pt_scene_clone_to_device(self._h, device, C.byref(h)), self._L)
+        return Scene(h, self._L)
+
+    def timings(self):
+        t = (C.c_double * 2)()
+        _check(self._L.pt_scene_timings(self._h, t), self._L)
+        return {"load_s": t[0], "hierarchy_build_s": t[1]}
 
     def set_skybox(self, path):
         """-SKYBOX: a 24-bit BMP sampled by rays that hit nothing (scene.cpp:126-154); None or "" removes it."""
@@ -307,6 +336,64 @@ class Session:
             self.close()
         except Exception:
             pass
+
+
+class Frame:
+    """pt_frame: one image on several devices from one host program -- row bands, one gather to the first device."""
+
+    def __init__(self, scene, devices, width, height, flags=0):
+        self._scene, self._L = scene, scene._L
+        self.width, self.height = width, height
+        devs = np.ascontiguousarray(devices, np.int32)
+        self._h = C.c_void_p()
+        _check(self._L.pt_frame_create(scene._h, _ip(devs), len(devs), width, height, flags, C.byref(self._h)), self._L)
+
+    def info(self):
+        n = C.c_int32()
+        _check(self._L.pt_frame_info(self._h, C.byref(n), None, None, None), self._L)
+        rows, dev, tr = np.zeros(2 * n.value, np.int32), np.zeros(n.value, np.int32), C.c_int32()
+        _check(self._L.pt_frame_info(self._h, C.byref(n), _ip(rows), _ip(dev), C.byref(tr)), self._L)
+        return {"bands": n.value, "rows": rows.reshape(-1, 2).tolist(), "devices": dev.tolist(), "transport": TRANSPORT_NAMES[tr.value]}
+
+    def render(self, pass_begin, pass_count, mrr, *, eps=1e-4, error=-1.0, seed=42, want_stats=False):
+        p = RenderParams(self.width, self.height, 0, self.height, pass_begin, pass_count, mrr, eps, error, seed, 0)
+        st = RenderStats()
+        _check(self._L.pt_frame_render(self._h, C.byref(p), C.byref(st) if want_stats else None), self._L)
+        return st.as_dict() if want_stats else None
+
+    def gather(self):
+        _check(self._L.pt_frame_gather(self._h), self._L)
+
+    def wait(self):
+        _check(self._L.pt_frame_wait(self._h), self._L)
+
+    def read(self):
+        n = self.width * self.height
+        s, s2, c = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        _check(self._L.pt_frame_read(self._h, _fp(s), _fp(s2), _ip(c)), self._L)
+        return s, s2, c
+
+    def clear(self):
+        _check(self._L.pt_frame_clear(self._h), self._L)
+
+    def close(self):
+        if self._h:
+            self._L.pt_frame_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rccl_version(library=None):
+    """ncclGetVersion of the RCCL the frame's gather would use; raises PtError if it cannot be loaded.  Needs no GPU."""
+    L = library or lib()
+    v = C.c_int32()
+    _check(L.pt_rccl_available(C.byref(v)), L)
+    return v.value
 
 
 def resolve(width, height, s, s2, c, gamma=None):

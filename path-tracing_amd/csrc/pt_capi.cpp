@@ -1,80 +1,22 @@
 // C ABI of libpt_hip.so (include/pt_hip.h).  Host side only: owns the device copies of the scene tables, maps HIP
-// errors to status codes, and implements the reference's host-side resolve and BMP writer.
-#include "../../include/pt_hip.h"
-
-#include <hip/hip_runtime_api.h>
+// errors to status codes, and implements the reference's host-side resolve and BMP writer.  (pt_frame.cpp holds the
+// multi-device frame on top of what is here.)
+#include "pt_capi_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <memory>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
 
 #include "pt_filters.hpp"
-#include "pt_kernels.hpp"
-#include "pt_scene.hpp"
-
-// Device copy of one CullTables (they depend on eps; a scene keeps the one of the last eps it rendered with).
-struct DeviceCull {
-    float eps = 0;
-    bool valid = false;
-    pt::CullTables host;
-    pt::ClusterDesc *clusters = nullptr;
-    pt::SphereRec *spheres = nullptr;
-    pt::CullRec *bary = nullptr;
-    pt::CullRec *bary_all = nullptr;
-    pt::ExactRec *exact_slot = nullptr;
-    pt::BvhNode *bvh = nullptr;
-};
-
-struct pt_scene {
-    pt::HostScene host;
-    pt::DeviceTables tables;
-    int device = -1;
-    DeviceCull cull;
-    pt::ExactRec *d_exact = nullptr;
-    pt::MatRec *d_mats = nullptr;
-    unsigned long long *d_stats = nullptr;
-    int cu_count = 256;            // compute units of the scene's device
-    uint32_t *d_sched = nullptr;   // ticket + per-tile chunk counters of the integrator's scheduler
-    size_t sched_words = 0;
-    std::vector<uint8_t> sky;   // skybox texels (B,G,R; top-down rows; no padding), empty = none
-    int sky_w = 0, sky_h = 0;
-    uint8_t *d_sky = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // The scheduler words, the statistics block and the timing events are per scene: launches of one scene are
-    // enqueued under launch_mutex and ordered on the device by ev_done, whatever streams the callers use.
-    std::mutex launch_mutex;
-    // pt_render_host: device band kept between calls + the stream its slab kernels run on (guarded by host_mutex)
-    std::mutex host_mutex;
-    float *d_host_band = nullptr;
-    size_t host_band_floats = 0;
-    hipStream_t host_stream = nullptr;
-    hipEvent_t ev_done = nullptr;
-    bool has_prev = false;
-    hipStream_t prev_stream = nullptr;
-};
 
 #ifdef PT_TEST_HOOKS
 static int g_items_per_slot = 0;
 #endif
 
-// A row band's accumulators kept on the device between pass slices (pt_session_*).
-struct pt_session {
-    pt_scene *scene = nullptr;
-    int32_t width = 0, height = 0, row_begin = 0, row_end = 0;
-    size_t n = 0;                 // pixels of the band
-    float *d_band = nullptr;      // sum[3n] | sum2[3n] | count[n], each plane 256-byte aligned
-    size_t plane_floats = 0;      // distance between the sum and sum2 planes, in floats
-    hipStream_t stream = nullptr;
-};
-
-namespace {
+namespace ptc {
 
 thread_local std::string g_error;
 
@@ -88,11 +30,67 @@ int hip_fail(hipError_t e, const char *what) {
                          : (e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP);
     return fail(code, std::string(what) + ": " + hipGetErrorString(e));
 }
-#define PT_HIP_TRY(expr)                                  \
-    do {                                                  \
-        hipError_t e_ = (expr);                           \
-        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
-    } while (0)
+
+void ctx_destroy(LaunchCtx &c) {
+    if (c.d_sched) (void)hipFree(c.d_sched);
+    if (c.d_stats) (void)hipFree(c.d_stats);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    if (c.ev_done) (void)hipEventDestroy(c.ev_done);
+    c.d_sched = nullptr;
+    c.d_stats = nullptr;
+    c.ev0 = c.ev1 = c.ev_done = nullptr;
+    c.sched_words = 0;
+    c.has_prev = false;
+}
+
+}  // namespace ptc
+
+using ptc::fail;
+using ptc::guarded;
+using ptc::hip_fail;
+
+namespace {
+
+// The layouts the kernels read pack indices into bit fields; a hierarchy that does not fit them must be refused, never
+// truncated: (ray, slot) pairs keep the slot in 24 bits (pt_kernels.hip: `e & 0xFFFFFF`), a box-tree node keeps its child
+// base in 21 bits (BvhNode::meta, `base << 11`; stack entries have 26), a sphere tree has at most kMaxLevels levels.
+int check_table_limits(unsigned long long n_slots, unsigned long long n_bvh_nodes, long long n_levels) {
+    if (n_slots >= (1ull << 24))
+        return fail(PT_ERR_UNSUPPORTED, "the culling hierarchy has " + std::to_string(n_slots) + " slots; (ray, slot) work items hold 24 bits");
+    if (n_bvh_nodes >= (1ull << 21))
+        return fail(PT_ERR_UNSUPPORTED, "the box tree has " + std::to_string(n_bvh_nodes) + " nodes; a node's child base holds 21 bits");
+    if (n_levels > pt::kMaxLevels)
+        return fail(PT_ERR_UNSUPPORTED, "a sphere tree has " + std::to_string(n_levels) + " levels; the walk holds " + std::to_string(pt::kMaxLevels));
+    return PT_OK;
+}
+
+// The culling hierarchy of a scene for one eps: built once per (scene, eps) on the host, whatever number of devices,
+// sessions or diagnostic calls ask for it.  (The test-hook build rebuilds every time: its mutations change the result.)
+int get_cull(pt_scene_host &h, float eps, std::shared_ptr<const pt::CullTables> &out) {
+    std::lock_guard<std::mutex> lock(h.cull_mutex);
+#ifndef PT_TEST_HOOKS
+    for (const auto &t : h.cull_cache)
+        if (std::memcmp(&t->eps, &eps, sizeof eps) == 0) {
+            out = t;
+            return PT_OK;
+        }
+#endif
+    const auto t0 = std::chrono::steady_clock::now();
+    auto t = std::make_shared<pt::CullTables>();
+    pt::build_cull_tables(h.host, eps, *t);
+    t->eps = eps;
+    h.cull_build_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    long long levels = 0;
+    for (const auto &c : t->clusters)
+        if (c.kind == 0) levels = std::max<long long>(levels, c.n_levels);
+    const int rc = check_table_limits(t->slot_tri.size(), t->bvh.size(), levels);
+    if (rc != PT_OK) return rc;
+    if (h.cull_cache.size() >= 4) h.cull_cache.erase(h.cull_cache.begin());
+    h.cull_cache.push_back(t);
+    out = t;
+    return PT_OK;
+}
 
 int upload(pt_scene *s, int device) {
     int n = 0;
@@ -102,17 +100,30 @@ int upload(pt_scene *s, int device) {
     if (device >= n) return fail(PT_ERR_NO_DEVICE, "device ordinal " + std::to_string(device) + " out of range");
     s->device = device;
     PT_HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->cu_count = prop.multiProcessorCount;
-    const auto &t = s->tables;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->cu_count = cus;
+    const auto &t = s->shared->tables;
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_exact), t.exact.size() * sizeof(pt::ExactRec) + 64));
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_mats), t.mats.size() * sizeof(pt::MatRec) + 64));
-    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stats), 24 * sizeof(unsigned long long)));
     if (!t.exact.empty()) PT_HIP_TRY(hipMemcpy(s->d_exact, t.exact.data(), t.exact.size() * sizeof(pt::ExactRec), hipMemcpyHostToDevice));
     if (!t.mats.empty()) PT_HIP_TRY(hipMemcpy(s->d_mats, t.mats.data(), t.mats.size() * sizeof(pt::MatRec), hipMemcpyHostToDevice));
-    PT_HIP_TRY(hipEventCreate(&s->ev0));
-    PT_HIP_TRY(hipEventCreate(&s->ev1));
-    PT_HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    const auto &sky = s->shared->sky;
+    if (!sky.empty()) {
+        PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_sky), sky.size() + 64));
+        PT_HIP_TRY(hipMemcpy(s->d_sky, sky.data(), sky.size(), hipMemcpyHostToDevice));
+    }
+    return PT_OK;
+}
+
+// events / statistics block of a launch context, on first use (the scene's device is current)
+int ctx_ready(LaunchCtx &c) {
+    if (!c.ev_done) PT_HIP_TRY(hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming));
+    return PT_OK;
+}
+int ctx_stats_ready(LaunchCtx &c) {
+    if (!c.d_stats) PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_stats), 24 * sizeof(unsigned long long)));
+    if (!c.ev0) PT_HIP_TRY(hipEventCreate(&c.ev0));
+    if (!c.ev1) PT_HIP_TRY(hipEventCreate(&c.ev1));
     return PT_OK;
 }
 
@@ -127,30 +138,32 @@ int upload_vec(const std::vector<T> &v, T **dst) {
     return PT_OK;
 }
 
-// The cull hierarchy's radii and margins depend on eps (-EPS): build and upload on first use, rebuild if eps changes.
+// The cull hierarchy's radii and margins depend on eps (-EPS): upload on first use, replace if eps changes.
 // Callers hold scene->launch_mutex from here until their kernel has been enqueued: a concurrent render with another eps
 // must not free the tables between this call and that launch.
 int ensure_cull(pt_scene *s, float eps) {
     DeviceCull &c = s->cull;
     if (c.valid && std::memcmp(&c.eps, &eps, sizeof eps) == 0) return PT_OK;
+    std::shared_ptr<const pt::CullTables> t;
+    int rc = get_cull(*s->shared, eps, t);
+    if (rc != PT_OK) return rc;
+    if (c.valid) PT_HIP_TRY(hipDeviceSynchronize());   // a previous launch may still read the old tables
     c.valid = false;
-    PT_HIP_TRY(hipDeviceSynchronize());   // a previous launch may still read the old tables
-    pt::build_cull_tables(s->host, eps, c.host);
-    int rc;
-    if ((rc = upload_vec(c.host.clusters, &c.clusters)) != PT_OK) return rc;
-    if ((rc = upload_vec(c.host.spheres, &c.spheres)) != PT_OK) return rc;
-    if ((rc = upload_vec(c.host.bary, &c.bary)) != PT_OK) return rc;
+    c.host = t;
+    if ((rc = upload_vec(t->clusters, &c.clusters)) != PT_OK) return rc;
+    if ((rc = upload_vec(t->spheres, &c.spheres)) != PT_OK) return rc;
+    if ((rc = upload_vec(t->bary, &c.bary)) != PT_OK) return rc;
     if (c.bary_all) {
         (void)hipFree(c.bary_all);
         c.bary_all = nullptr;
     }
-    if (!c.host.bary_all.empty() && (rc = upload_vec(c.host.bary_all, &c.bary_all)) != PT_OK) return rc;
-    if ((rc = upload_vec(c.host.exact_slot, &c.exact_slot)) != PT_OK) return rc;
+    if (!t->bary_all.empty() && (rc = upload_vec(t->bary_all, &c.bary_all)) != PT_OK) return rc;
+    if ((rc = upload_vec(t->exact_slot, &c.exact_slot)) != PT_OK) return rc;
     if (c.bvh) {
         (void)hipFree(c.bvh);
         c.bvh = nullptr;
     }
-    if (!c.host.bvh.empty() && (rc = upload_vec(c.host.bvh, &c.bvh)) != PT_OK) return rc;
+    if (!t->bvh.empty() && (rc = upload_vec(t->bvh, &c.bvh)) != PT_OK) return rc;
     c.eps = eps;
     c.valid = true;
     return PT_OK;
@@ -162,11 +175,12 @@ struct SceneDeleter {
 using ScenePtr = std::unique_ptr<pt_scene, SceneDeleter>;   // frees host and device side on every early return / exception
 
 int finish_scene(ScenePtr s, int device, pt_scene **out) {
-    if (s->host.n_tri() >= (1 << 23))   // work items carry a slot index in 24 bits, and the box tree pads its leaves to 8 slots
+    pt_scene_host &h = *s->shared;
+    if (h.host.n_tri() >= (1 << 23))   // a first, cheap bound; what the layouts really hold is checked on the built hierarchy (get_cull)
         return fail(PT_ERR_INVALID_ARGUMENT, "more than 8 388 607 triangles");
-    for (int m : s->host.tri_mat)
-        if (m < 0 || m >= s->host.n_mat()) return fail(PT_ERR_INVALID_ARGUMENT, "triangle refers to material " + std::to_string(m));
-    pt::build_device_tables(s->host, s->tables);
+    for (int m : h.host.tri_mat)
+        if (m < 0 || m >= h.host.n_mat()) return fail(PT_ERR_INVALID_ARGUMENT, "triangle refers to material " + std::to_string(m));
+    pt::build_device_tables(h.host, h.tables);
     if (device >= 0) {
         const int rc = upload(s.get(), device);
         if (rc != PT_OK) return rc;
@@ -178,7 +192,8 @@ int finish_scene(ScenePtr s, int device, pt_scene **out) {
 // The part of the kernel arguments that describes the scene (its tables for the current eps).
 void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     std::memset(&a, 0, sizeof a);
-    const pt::CullConstants &cc = scene->cull.host.cc, &ca = scene->cull.host.cc_all;
+    const pt::CullTables &t = *scene->cull.host;
+    const pt::CullConstants &cc = t.cc, &ca = t.cc_all;
     a.clusters = scene->cull.clusters;
     a.spheres = scene->cull.spheres;
     a.bary = scene->cull.bary;
@@ -187,42 +202,156 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.exact = scene->d_exact;
     a.exact_slot = scene->cull.exact_slot;
     a.bvh = scene->cull.bvh;
-    a.bvh_leaf0 = scene->cull.host.bvh_leaf0;
-    a.n_bvh = static_cast<uint32_t>(scene->cull.host.bvh.size());
-    a.bvh_err = scene->cull.host.bvh_err;
+    a.bvh_leaf0 = t.bvh_leaf0;
+    a.n_bvh = static_cast<uint32_t>(t.bvh.size());
+    a.bvh_err = t.bvh_err;
     a.mats = scene->d_mats;
     a.sky = scene->d_sky;
-    a.sky_w = scene->sky_w;
-    a.sky_h = scene->sky_h;
-    a.n_clusters = static_cast<int32_t>(scene->cull.host.clusters.size());
-    a.n_tri = scene->host.n_tri();
-    a.n_slots = static_cast<uint32_t>(scene->cull.host.slot_tri.size());
+    a.sky_w = scene->d_sky ? scene->shared->sky_w : 0;
+    a.sky_h = scene->d_sky ? scene->shared->sky_h : 0;
+    a.n_clusters = static_cast<int32_t>(t.clusters.size());
+    a.n_tri = scene->shared->host.n_tri();
+    a.n_slots = static_cast<uint32_t>(t.slot_tri.size());
     a.eps = eps;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.m0_quad = cc.m0_quad; a.t_guard = cc.t_guard;
-    a.r_org = scene->cull.host.r_org;
-    a.may_leave_envelope = scene->cull.host.may_leave_envelope ? 1 : 0;
+    a.r_org = t.r_org;
+    a.may_leave_envelope = t.may_leave_envelope ? 1 : 0;
     a.last_segment_filter = 1;
 #ifdef PT_TEST_HOOKS
     if (pt::g_cull_mutation.no_last_segment_filter) a.last_segment_filter = 0;
 #endif
-    a.emis_clusters = scene->cull.host.emis_clusters;
-    a.emis_large_w0 = scene->cull.host.emis_large_w0;
-    a.emis_bvh = scene->cull.host.emis_bvh ? 1u : 0u;
+    a.emis_clusters = t.emis_clusters;
+    a.emis_large_w0 = t.emis_large_w0;
+    a.emis_bvh = t.emis_bvh ? 1u : 0u;
 }
 
-// No exception may cross the C boundary: allocation failures and anything else become status codes.
-template <class F>
-int guarded(F &&f) noexcept {
-    try {
-        return f();
-    } catch (const std::bad_alloc &) {
-        return fail(PT_ERR_OUT_OF_MEMORY, "out of host memory");
-    } catch (const std::exception &e) {
-        return fail(PT_ERR_INVALID_ARGUMENT, std::string("internal error: ") + e.what());
-    } catch (...) {
-        return fail(PT_ERR_INVALID_ARGUMENT, "internal error");
-    }
+void zero_stats(const pt_scene *scene, pt_render_stats *stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->n_triangles = scene->shared->host.n_tri();
 }
+
+// Enqueue one integrator launch on `stream` for the context `ctx` (its scheduler words, its statistics block).  Never waits
+// for the device except to grow the scheduler words.  The caller holds ctx.mutex.
+int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, float *d_sum, float *d_sum2, int32_t *d_count,
+                   hipStream_t stream, bool want_stats) {
+    ctx.stats_pending = false;
+    ctx.last_chunks = 0;
+    PT_HIP_TRY(hipSetDevice(scene->device));
+    std::lock_guard<std::mutex> launch_lock(scene->launch_mutex);
+    const int crc = ensure_cull(scene, p->eps);
+    if (crc != PT_OK) return crc;
+    pt::RenderArgs a;
+    fill_scene_args(scene, p->eps, a);
+    a.vec_ok = (p->width % 4 == 0) &&
+               ((reinterpret_cast<uintptr_t>(d_sum) | reinterpret_cast<uintptr_t>(d_sum2) | reinterpret_cast<uintptr_t>(d_count)) % 16 == 0);
+    a.sum = d_sum;
+    a.sum2 = d_sum2;
+    a.count = d_count;
+    a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+    a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
+    a.error = p->error; a.seed = p->seed;
+    a.blocks_x = (p->width + pt::kTileW - 1) / pt::kTileW;
+    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
+    if (n_tiles == 0) return PT_OK;
+    int rc = ctx_ready(ctx);
+    if (rc != PT_OK) return rc;
+    if (want_stats) {
+        if ((rc = ctx_stats_ready(ctx)) != PT_OK) return rc;
+        a.stats = ctx.d_stats;
+    }
+    // Scheduler: cut the pass range into chunks so that the tail of the launch is balanced with small work items.  A tile's
+    // chunks run in order and each re-reads and re-writes the tile's accumulators, so there should be few of them: chunk c
+    // takes 3/4 of the passes that are left (256 passes: 192 + 48 + 16), the last one at least 4 and less than 32.
+    // Wave slots of the chip FOR THE INSTANTIATION THIS LAUNCH RUNS: its occupancy is the compiler's and the LDS budget's
+    // business, asked from the runtime once per instantiation instead of assumed.
+    int waves_per_cu = 24;
+    PT_HIP_TRY(pt::integrator_waves_per_cu(a, &waves_per_cu));
+    const uint32_t slots = static_cast<uint32_t>(scene->cu_count) * static_cast<uint32_t>(std::max(1, waves_per_cu));
+    uint32_t n_chunks = 1;
+    int32_t chunk_passes = 0;
+    if (n_tiles >= slots / 2u)
+        while (n_chunks < 6u && (p->pass_count >> (2u * n_chunks)) >= 8) ++n_chunks;
+#ifdef PT_TEST_HOOKS
+    if (g_items_per_slot > 0) {   // scheduler tuning, test build only: equal chunks, about items_per_slot work items per wave slot
+        n_chunks = (static_cast<uint32_t>(g_items_per_slot) * slots + n_tiles - 1u) / n_tiles;
+        n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
+        chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
+        n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
+    }
+#endif
+    if (static_cast<unsigned long long>(n_tiles) * n_chunks > 0x7fffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "too many work items");
+    if (ctx.has_prev && ctx.prev_stream != stream) PT_HIP_TRY(hipStreamWaitEvent(stream, ctx.ev_done, 0));
+    if (ctx.sched_words < 1 + static_cast<size_t>(n_tiles)) {
+        if (ctx.has_prev) PT_HIP_TRY(hipStreamSynchronize(stream));   // an earlier launch of this context may still use the old words
+        if (ctx.d_sched) (void)hipFree(ctx.d_sched);
+        ctx.d_sched = nullptr;
+        ctx.sched_words = 0;
+        PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx.d_sched), (1 + static_cast<size_t>(n_tiles)) * sizeof(uint32_t)));
+        ctx.sched_words = 1 + static_cast<size_t>(n_tiles);
+    }
+    PT_HIP_TRY(hipMemsetAsync(ctx.d_sched, 0, (1 + static_cast<size_t>(n_tiles)) * sizeof(uint32_t), stream));
+    a.sched = ctx.d_sched;
+    a.n_tiles = n_tiles;
+    a.n_chunks = n_chunks;
+    a.chunk_passes = chunk_passes;
+    if (want_stats) {
+        PT_HIP_TRY(hipMemsetAsync(ctx.d_stats, 0, 24 * sizeof(unsigned long long), stream));
+        PT_HIP_TRY(hipEventRecord(ctx.ev0, stream));
+    }
+    PT_HIP_TRY(pt::launch_integrator(a, stream));
+    if (want_stats) PT_HIP_TRY(hipEventRecord(ctx.ev1, stream));
+    PT_HIP_TRY(hipEventRecord(ctx.ev_done, stream));
+    ctx.has_prev = true;
+    ctx.prev_stream = stream;
+    ctx.last_chunks = n_chunks;
+    ctx.stats_pending = want_stats;
+    return PT_OK;
+}
+
+// Wait for the launch enqueue_render put on `stream` and read its statistics.  The caller holds ctx.mutex.
+int collect_stats(pt_scene *scene, LaunchCtx &ctx, hipStream_t stream, pt_render_stats *stats) {
+    zero_stats(scene, stats);
+    if (!ctx.stats_pending) return PT_OK;   // an empty band
+    ctx.stats_pending = false;
+    PT_HIP_TRY(hipSetDevice(scene->device));
+    unsigned long long h[24];
+    PT_HIP_TRY(hipMemcpyAsync(h, ctx.d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
+    PT_HIP_TRY(hipStreamSynchronize(stream));
+    float ms = -1.0f;
+    PT_HIP_TRY(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+    stats->samples_traced = h[0];
+    stats->segments = h[1];
+    stats->contributing = h[2];
+    stats->exact_tests = h[3];
+    stats->misses = h[4];
+    stats->wave_segments = h[5];
+    stats->wave_node_rounds = h[6];
+    stats->wave_exact_iterations = h[7];
+    stats->kernel_ms = ms;
+    stats->n_chunks = static_cast<int32_t>(ctx.last_chunks);
+    stats->partial_commit_rounds = static_cast<int32_t>(std::min<unsigned long long>(h[8], 0x7fffffffull));
+    stats->verify_checked = h[9];      // both stay 0 unless this is a verification build (-DPT_VERIFY_BRUTE / -DPT_VERIFY_SHIPPED)
+    stats->verify_mismatches = h[10];
+#ifdef PT_TEST_HOOKS
+    if (h[10] != 0) {   // verification build: one disagreeing segment, for diagnosis
+        auto f = [](unsigned long long w, int hi) { const uint32_t b = static_cast<uint32_t>(hi ? w >> 32 : w); float x; std::memcpy(&x, &b, 4); return x; };
+        std::fprintf(stderr, "PT_VERIFY example: all-triangles loop -> triangle %d (key %016llx), culled search -> triangle %d (key %016llx); "
+                             "ray o = (%.9g, %.9g, %.9g) d = (%.9g, %.9g, %.9g)\n",
+                     static_cast<int>(h[11] & 0xFFFFFFFFu), h[11], static_cast<int>(h[12] & 0xFFFFFFFFu), h[12],
+                     f(h[13], 1), f(h[13], 0), f(h[14], 1), f(h[14], 0), f(h[15], 1), f(h[15], 0));
+    }
+#endif
+#ifdef PT_PHASE_TIMERS
+    std::fprintf(stderr, "PT_PHASE_TIMERS cycles:");
+    for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[16 + k]);
+    std::fprintf(stderr, "\n");
+#endif
+    return PT_OK;
+}
+
+}  // namespace
+
+namespace ptc {
 
 int check_params(const pt_scene *scene, const pt_render_params *p) {
     if (!scene || !p) return fail(PT_ERR_INVALID_ARGUMENT, "null scene or params");
@@ -240,7 +369,58 @@ int check_params(const pt_scene *scene, const pt_render_params *p) {
     return PT_OK;
 }
 
-}  // namespace
+int session_create_on(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, float *d_sum,
+                      float *d_sum2, int32_t *d_count, pt_session **out) {
+    if (!out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    pt_render_params p;
+    std::memset(&p, 0, sizeof p);
+    p.width = width; p.height = height; p.row_begin = row_begin; p.row_end = row_end;
+    const int rc = check_params(scene, &p);
+    if (rc != PT_OK) return rc;
+    PT_HIP_TRY(hipSetDevice(scene->device));
+    std::unique_ptr<pt_session> s(new pt_session);
+    s->scene = scene;
+    s->width = width; s->height = height; s->row_begin = row_begin; s->row_end = row_end;
+    s->n = static_cast<size_t>(row_end - row_begin) * width;
+    PT_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    hipError_t e = hipSuccess;
+    if (d_sum) {   // borrowed planes: the caller zeroes and frees them
+        s->d_sum = d_sum; s->d_sum2 = d_sum2; s->d_count = d_count;
+    } else {
+        const size_t plane_floats = (3 * s->n + 63) / 64 * 64;
+        const size_t bytes = (2 * plane_floats + s->n) * sizeof(float) + 256;
+        e = hipMalloc(reinterpret_cast<void **>(&s->d_band), bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(s->d_band, 0, bytes, s->stream);
+        s->d_sum = s->d_band; s->d_sum2 = s->d_band + plane_floats;
+        s->d_count = reinterpret_cast<int32_t *>(s->d_band + 2 * plane_floats);
+    }
+    if (e != hipSuccess) {
+        if (s->d_band) (void)hipFree(s->d_band);
+        (void)hipStreamDestroy(s->stream);
+        return hip_fail(e, "pt_session_create");
+    }
+    *out = s.release();
+    return PT_OK;
+}
+
+int session_enqueue(pt_session *s, const pt_render_params *p, bool want_stats) {
+    if (!s || !p) return fail(PT_ERR_INVALID_ARGUMENT, "null session or params");
+    if (p->width != s->width || p->height != s->height || p->row_begin != s->row_begin || p->row_end != s->row_end)
+        return fail(PT_ERR_INVALID_ARGUMENT, "params describe another band than the session's");
+    const int rc = check_params(s->scene, p);
+    if (rc != PT_OK) return rc;
+    return enqueue_render(s->scene, s->ctx, p, s->d_sum, s->d_sum2, s->d_count, s->stream, want_stats);
+}
+
+int session_collect(pt_session *s, pt_render_stats *stats) {
+    if (!s || !stats) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    return collect_stats(s->scene, s->ctx, s->stream, stats);
+}
+
+}  // namespace ptc
+
+using ptc::check_params;
 
 extern "C" {
 
@@ -249,7 +429,7 @@ int pt_abi_version(void) { return PT_ABI_VERSION; }
 void *pt_host_alloc(size_t bytes) {
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
-        g_error = "pt_host_alloc: hipHostMalloc failed";
+        ptc::g_error = "pt_host_alloc: hipHostMalloc failed";
         return nullptr;
     }
     return p;
@@ -265,16 +445,33 @@ int pt_device_count(void) {
     return n;
 }
 
-const char *pt_last_error(void) { return g_error.c_str(); }
+const char *pt_last_error(void) { return ptc::g_error.c_str(); }
+
+int pt_scene_timings(const pt_scene *scene, double *seconds) {
+    if (!scene || !seconds) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(scene->shared->cull_mutex);
+    seconds[0] = scene->shared->load_seconds;
+    seconds[1] = scene->shared->cull_build_seconds;
+    return PT_OK;
+}
+
+int pt_table_limits_check(uint64_t n_slots, uint64_t n_bvh_nodes, int32_t n_levels) {
+    return guarded([&] { return check_table_limits(n_slots, n_bvh_nodes, n_levels); });
+}
 
 static int scene_load_obj_impl(const char *model_dir, const char *model_name, int device, pt_scene **out) {
     if (!model_dir || !model_name || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     ScenePtr s(new pt_scene);
+    s->shared = std::make_shared<pt_scene_host>();
     std::string err;
     bool io = false;
-    if (!pt::load_obj(model_dir, model_name, s->host, err, io)) return fail(io ? PT_ERR_IO : PT_ERR_PARSE, err);
-    return finish_scene(std::move(s), device, out);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!pt::load_obj(model_dir, model_name, s->shared->host, err, io)) return fail(io ? PT_ERR_IO : PT_ERR_PARSE, err);
+    pt_scene_host *h = s->shared.get();
+    const int rc = finish_scene(std::move(s), device, out);
+    h->load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();   // (includes the first device's upload)
+    return rc;
 }
 
 static int scene_create_impl(const float *triangles, const int32_t *triangle_material, int32_t n_triangles, const float *materials,
@@ -284,10 +481,25 @@ static int scene_create_impl(const float *triangles, const int32_t *triangle_mat
         return fail(PT_ERR_INVALID_ARGUMENT, "null table or negative count");
     *out = nullptr;
     ScenePtr s(new pt_scene);
-    s->host.tri.assign(triangles, triangles + static_cast<size_t>(n_triangles) * PT_TRIANGLE_FLOATS);
-    s->host.tri_mat.assign(triangle_material, triangle_material + n_triangles);
-    s->host.mat.assign(materials, materials + static_cast<size_t>(n_materials) * PT_MATERIAL_FLOATS);
+    s->shared = std::make_shared<pt_scene_host>();
+    pt::HostScene &h = s->shared->host;
+    h.tri.assign(triangles, triangles + static_cast<size_t>(n_triangles) * PT_TRIANGLE_FLOATS);
+    h.tri_mat.assign(triangle_material, triangle_material + n_triangles);
+    h.mat.assign(materials, materials + static_cast<size_t>(n_materials) * PT_MATERIAL_FLOATS);
     return finish_scene(std::move(s), device, out);
+}
+
+static int scene_clone_impl(const pt_scene *src, int device, pt_scene **out) {
+    if (!src || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    ScenePtr s(new pt_scene);
+    s->shared = src->shared;   // parsed model, tables, hierarchies built so far, skybox texels
+    if (device >= 0) {
+        const int rc = upload(s.get(), device);
+        if (rc != PT_OK) return rc;
+    }
+    *out = s.release();
+    return PT_OK;
 }
 
 static int scene_set_skybox_bmp_impl(pt_scene *scene, const char *path) {
@@ -343,29 +555,31 @@ static int scene_set_skybox_bmp_impl(pt_scene *scene, const char *path) {
             PT_HIP_TRY(hipMemcpy(scene->d_sky, texels.data(), texels.size(), hipMemcpyHostToDevice));
         }
     }
-    scene->sky.swap(texels);
-    scene->sky_w = w;
-    scene->sky_h = h;
+    // (per-device copies made from this scene AFTERWARDS inherit the skybox; copies made before keep what they had)
+    scene->shared->sky.swap(texels);
+    scene->shared->sky_w = w;
+    scene->shared->sky_h = h;
     return PT_OK;
 }
 
 int pt_scene_counts(const pt_scene *scene, int32_t *n_triangles, int32_t *n_materials) {
     if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
-    if (n_triangles) *n_triangles = scene->host.n_tri();
-    if (n_materials) *n_materials = scene->host.n_mat();
+    if (n_triangles) *n_triangles = scene->shared->host.n_tri();
+    if (n_materials) *n_materials = scene->shared->host.n_mat();
     return PT_OK;
 }
 
 int pt_scene_get_triangles(const pt_scene *scene, float *triangles, int32_t *triangle_material) {
     if (!scene) return fail(PT_ERR_INVALID_ARGUMENT, "null scene");
-    if (triangles) std::memcpy(triangles, scene->host.tri.data(), scene->host.tri.size() * sizeof(float));
-    if (triangle_material) std::memcpy(triangle_material, scene->host.tri_mat.data(), scene->host.tri_mat.size() * sizeof(int32_t));
+    const pt::HostScene &h = scene->shared->host;
+    if (triangles) std::memcpy(triangles, h.tri.data(), h.tri.size() * sizeof(float));
+    if (triangle_material) std::memcpy(triangle_material, h.tri_mat.data(), h.tri_mat.size() * sizeof(int32_t));
     return PT_OK;
 }
 
 int pt_scene_get_materials(const pt_scene *scene, float *materials) {
     if (!scene || !materials) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-    std::memcpy(materials, scene->host.mat.data(), scene->host.mat.size() * sizeof(float));
+    std::memcpy(materials, scene->shared->host.mat.data(), scene->shared->host.mat.size() * sizeof(float));
     return PT_OK;
 }
 
@@ -381,14 +595,10 @@ void pt_scene_destroy(pt_scene *s) {
         if (s->cull.bvh) (void)hipFree(s->cull.bvh);
         if (s->d_exact) (void)hipFree(s->d_exact);
         if (s->d_mats) (void)hipFree(s->d_mats);
-        if (s->d_stats) (void)hipFree(s->d_stats);
         if (s->d_sky) (void)hipFree(s->d_sky);
-        if (s->d_sched) (void)hipFree(s->d_sched);
         if (s->d_host_band) (void)hipFree(s->d_host_band);
         if (s->host_stream) (void)hipStreamDestroy(s->host_stream);
-        if (s->ev0) (void)hipEventDestroy(s->ev0);
-        if (s->ev1) (void)hipEventDestroy(s->ev1);
-        if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+        ptc::ctx_destroy(s->ctx);
     }
     delete s;
 }
@@ -398,107 +608,11 @@ static int render_device_impl(pt_scene *scene, const pt_render_params *p, float 
     const int rc = check_params(scene, p);
     if (rc != PT_OK) return rc;
     if (!d_sum || !d_sum2 || !d_count) return fail(PT_ERR_INVALID_ARGUMENT, "null accumulator pointer");
-    PT_HIP_TRY(hipSetDevice(scene->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    std::lock_guard<std::mutex> launch_lock(scene->launch_mutex);
-    const int crc = ensure_cull(scene, p->eps);
-    if (crc != PT_OK) return crc;
-    pt::RenderArgs a;
-    fill_scene_args(scene, p->eps, a);
-    a.vec_ok = (p->width % 4 == 0) &&
-               ((reinterpret_cast<uintptr_t>(d_sum) | reinterpret_cast<uintptr_t>(d_sum2) | reinterpret_cast<uintptr_t>(d_count)) % 16 == 0);
-    a.sum = d_sum;
-    a.sum2 = d_sum2;
-    a.count = d_count;
-    a.stats = stats ? scene->d_stats : nullptr;
-    a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
-    a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
-    a.error = p->error; a.seed = p->seed;
-    a.blocks_x = (p->width + pt::kTileW - 1) / pt::kTileW;
-    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
-    if (n_tiles == 0) {
-        if (stats) {
-            std::memset(stats, 0, sizeof *stats);
-            stats->n_triangles = scene->host.n_tri();
-        }
-        return PT_OK;
-    }
-    // Scheduler: cut the pass range into chunks so that the tail of the launch is balanced with small work items.  A tile's
-    // chunks run in order and each re-reads and re-writes the tile's accumulators, so there should be few of them: chunk c
-    // takes 3/4 of the passes that are left (256 passes: 192 + 48 + 16), the last one at least 4 and less than 32.
-    const uint32_t slots = static_cast<uint32_t>(scene->cu_count) * 4u * 6u;   // CUs x SIMDs x waves per SIMD of this kernel
-    uint32_t n_chunks = 1;
-    int32_t chunk_passes = 0;
-    if (n_tiles >= slots / 2u)
-        while (n_chunks < 6u && (p->pass_count >> (2u * n_chunks)) >= 8) ++n_chunks;
-#ifdef PT_TEST_HOOKS
-    if (g_items_per_slot > 0) {   // scheduler tuning, test build only: equal chunks, about items_per_slot work items per wave slot
-        n_chunks = (static_cast<uint32_t>(g_items_per_slot) * slots + n_tiles - 1u) / n_tiles;
-        n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
-        chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
-        n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
-    }
-#endif
-    if (static_cast<unsigned long long>(n_tiles) * n_chunks > 0x7fffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "too many work items");
-    if (scene->has_prev && scene->prev_stream != stream) PT_HIP_TRY(hipStreamWaitEvent(stream, scene->ev_done, 0));
-    if (scene->sched_words < 1 + static_cast<size_t>(n_tiles)) {
-        PT_HIP_TRY(hipStreamSynchronize(stream));
-        if (scene->d_sched) (void)hipFree(scene->d_sched);
-        scene->d_sched = nullptr;
-        scene->sched_words = 0;
-        PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scene->d_sched), (1 + static_cast<size_t>(n_tiles)) * sizeof(uint32_t)));
-        scene->sched_words = 1 + static_cast<size_t>(n_tiles);
-    }
-    PT_HIP_TRY(hipMemsetAsync(scene->d_sched, 0, (1 + static_cast<size_t>(n_tiles)) * sizeof(uint32_t), stream));
-    a.sched = scene->d_sched;
-    a.n_tiles = n_tiles;
-    a.n_chunks = n_chunks;
-    a.chunk_passes = chunk_passes;
-    if (stats) {
-        PT_HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 24 * sizeof(unsigned long long), stream));
-        PT_HIP_TRY(hipEventRecord(scene->ev0, stream));
-    }
-    PT_HIP_TRY(pt::launch_integrator(a, stream));
-    PT_HIP_TRY(hipEventRecord(scene->ev_done, stream));
-    scene->has_prev = true;
-    scene->prev_stream = stream;
-    if (stats) {
-        PT_HIP_TRY(hipEventRecord(scene->ev1, stream));
-        unsigned long long h[24];
-        PT_HIP_TRY(hipMemcpyAsync(h, scene->d_stats, sizeof h, hipMemcpyDeviceToHost, stream));
-        PT_HIP_TRY(hipStreamSynchronize(stream));
-        float ms = -1.0f;
-        PT_HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
-        stats->samples_traced = h[0];
-        stats->segments = h[1];
-        stats->contributing = h[2];
-        stats->exact_tests = h[3];
-        stats->misses = h[4];
-        stats->wave_segments = h[5];
-        stats->wave_node_rounds = h[6];
-        stats->wave_exact_iterations = h[7];
-        stats->kernel_ms = ms;
-        stats->n_triangles = scene->host.n_tri();
-        stats->n_chunks = static_cast<int32_t>(n_chunks);
-        stats->partial_commit_rounds = static_cast<int32_t>(std::min<unsigned long long>(h[8], 0x7fffffffull));
-        stats->verify_checked = h[9];      // both stay 0 unless this is the verification build (-DPT_VERIFY_BRUTE)
-        stats->verify_mismatches = h[10];
-#ifdef PT_TEST_HOOKS
-        if (h[10] != 0) {   // verification build: one disagreeing segment, for diagnosis
-            auto f = [](unsigned long long w, int hi) { const uint32_t b = static_cast<uint32_t>(hi ? w >> 32 : w); float x; std::memcpy(&x, &b, 4); return x; };
-            std::fprintf(stderr, "PT_VERIFY example: all-triangles loop -> triangle %d (key %016llx), culled search -> triangle %d (key %016llx); "
-                                 "ray o = (%.9g, %.9g, %.9g) d = (%.9g, %.9g, %.9g)\n",
-                         static_cast<int>(h[11] & 0xFFFFFFFFu), h[11], static_cast<int>(h[12] & 0xFFFFFFFFu), h[12],
-                         f(h[13], 1), f(h[13], 0), f(h[14], 1), f(h[14], 0), f(h[15], 1), f(h[15], 0));
-        }
-#endif
-#ifdef PT_PHASE_TIMERS
-        std::fprintf(stderr, "PT_PHASE_TIMERS cycles:");
-        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h[16 + k]);
-        std::fprintf(stderr, "\n");
-#endif
-    }
-    return PT_OK;
+    std::lock_guard<std::mutex> ctx_lock(scene->ctx.mutex);
+    const int r = enqueue_render(scene, scene->ctx, p, d_sum, d_sum2, d_count, stream, stats != nullptr);
+    if (r != PT_OK || !stats) return r;
+    return collect_stats(scene, scene->ctx, stream, stats);
 }
 
 static int trace_rays_host_impl(pt_scene *scene, int32_t n_rays, const float *origins, const float *directions, float eps,
@@ -545,10 +659,7 @@ static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *s
     const int rows = p->row_end - p->row_begin;
     const size_t W = static_cast<size_t>(p->width), n = static_cast<size_t>(rows) * W;
     if (n == 0) {
-        if (stats) {
-            std::memset(stats, 0, sizeof *stats);
-            stats->n_triangles = scene->host.n_tri();
-        }
+        if (stats) zero_stats(scene, stats);
         return PT_OK;
     }
     std::lock_guard<std::mutex> host_lock(scene->host_mutex);
@@ -581,39 +692,12 @@ static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *s
     return PT_OK;
 }
 
-static int session_create_impl(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, pt_session **out) {
-    if (!out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-    *out = nullptr;
-    pt_render_params p;
-    std::memset(&p, 0, sizeof p);
-    p.width = width; p.height = height; p.row_begin = row_begin; p.row_end = row_end;
-    const int rc = check_params(scene, &p);
-    if (rc != PT_OK) return rc;
-    PT_HIP_TRY(hipSetDevice(scene->device));
-    std::unique_ptr<pt_session> s(new pt_session);
-    s->scene = scene;
-    s->width = width; s->height = height; s->row_begin = row_begin; s->row_end = row_end;
-    s->n = static_cast<size_t>(row_end - row_begin) * width;
-    s->plane_floats = (3 * s->n + 63) / 64 * 64;
-    const size_t bytes = (2 * s->plane_floats + s->n) * sizeof(float) + 256;
-    PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_band), bytes));
-    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMemsetAsync(s->d_band, 0, bytes, s->stream);
-    if (e != hipSuccess) {
-        (void)hipFree(s->d_band);
-        if (s->stream) (void)hipStreamDestroy(s->stream);
-        return hip_fail(e, "pt_session_create");
-    }
-    *out = s.release();
-    return PT_OK;
-}
-
 static int session_render_impl(pt_session *s, const pt_render_params *p, pt_render_stats *stats) {
-    if (!s || !p) return fail(PT_ERR_INVALID_ARGUMENT, "null session or params");
-    if (p->width != s->width || p->height != s->height || p->row_begin != s->row_begin || p->row_end != s->row_end)
-        return fail(PT_ERR_INVALID_ARGUMENT, "params describe another band than the session's");
-    return render_device_impl(s->scene, p, s->d_band, s->d_band + s->plane_floats,
-                              reinterpret_cast<int32_t *>(s->d_band + 2 * s->plane_floats), s->stream, stats);
+    if (!s) return fail(PT_ERR_INVALID_ARGUMENT, "null session or params");
+    std::lock_guard<std::mutex> ctx_lock(s->ctx.mutex);
+    const int r = ptc::session_enqueue(s, p, stats != nullptr);
+    if (r != PT_OK || !stats) return r;
+    return ptc::session_collect(s, stats);
 }
 
 static int session_read_impl(pt_session *s, float *sum, float *sum2, int32_t *count) {
@@ -623,24 +707,29 @@ static int session_read_impl(pt_session *s, float *sum, float *sum2, int32_t *co
     // wait for the session's kernels, then plain synchronous copies: the runtime's fast path for pageable destinations
     // (hipMemcpyAsync into pageable memory ran at about 1 GB/s here)
     PT_HIP_TRY(hipStreamSynchronize(s->stream));
-    PT_HIP_TRY(hipMemcpy(sum, s->d_band, 3 * s->n * sizeof(float), hipMemcpyDeviceToHost));
-    PT_HIP_TRY(hipMemcpy(sum2, s->d_band + s->plane_floats, 3 * s->n * sizeof(float), hipMemcpyDeviceToHost));
-    PT_HIP_TRY(hipMemcpy(count, s->d_band + 2 * s->plane_floats, s->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(sum, s->d_sum, 3 * s->n * sizeof(float), hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(sum2, s->d_sum2, 3 * s->n * sizeof(float), hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(count, s->d_count, s->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
 static int session_clear_impl(pt_session *s) {
     if (!s) return fail(PT_ERR_INVALID_ARGUMENT, "null session");
     PT_HIP_TRY(hipSetDevice(s->scene->device));
-    PT_HIP_TRY(hipMemsetAsync(s->d_band, 0, (2 * s->plane_floats + s->n) * sizeof(float), s->stream));
+    PT_HIP_TRY(hipMemsetAsync(s->d_sum, 0, 3 * s->n * sizeof(float), s->stream));
+    PT_HIP_TRY(hipMemsetAsync(s->d_sum2, 0, 3 * s->n * sizeof(float), s->stream));
+    PT_HIP_TRY(hipMemsetAsync(s->d_count, 0, s->n * sizeof(int32_t), s->stream));
     return PT_OK;
 }
+
 
 static int scene_cull_tables_impl(pt_scene *scene, float eps, int32_t *counts, float *clusters, float *spheres, float *bary,
                          float *constants) {
     if (!scene || !counts) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-    pt::CullTables t;
-    pt::build_cull_tables(scene->host, eps, t);
+    std::shared_ptr<const pt::CullTables> tp;
+    const int rc = get_cull(*scene->shared, eps, tp);
+    if (rc != PT_OK) return rc;
+    const pt::CullTables &t = *tp;
     counts[0] = static_cast<int32_t>(t.clusters.size());
     counts[1] = static_cast<int32_t>(t.spheres.size());
     counts[2] = static_cast<int32_t>(t.bary.size());
@@ -660,8 +749,10 @@ static int scene_cull_tables_impl(pt_scene *scene, float eps, int32_t *counts, f
 
 static int scene_cull_layout_impl(pt_scene *scene, float eps, int32_t *counts, int32_t *slot_triangle, void *bvh_nodes) {
     if (!scene || !counts) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-    pt::CullTables t;
-    pt::build_cull_tables(scene->host, eps, t);
+    std::shared_ptr<const pt::CullTables> tp;
+    const int rc = get_cull(*scene->shared, eps, tp);
+    if (rc != PT_OK) return rc;
+    const pt::CullTables &t = *tp;
     counts[0] = static_cast<int32_t>(t.slot_tri.size());
     counts[1] = static_cast<int32_t>(t.bvh.size());
     counts[2] = static_cast<int32_t>(t.bvh_leaf0);
@@ -843,6 +934,10 @@ int pt_scene_create(const float *triangles, const int32_t *triangle_material, in
     return guarded([&] { return scene_create_impl(triangles, triangle_material, n_triangles, materials, n_materials, device, out); });
 }
 
+int pt_scene_clone_to_device(const pt_scene *scene, int device, pt_scene **out) {
+    return guarded([&] { return scene_clone_impl(scene, device, out); });
+}
+
 int pt_scene_set_skybox_bmp(pt_scene *scene, const char *path) {
     return guarded([&] { return scene_set_skybox_bmp_impl(scene, path); });
 }
@@ -860,7 +955,7 @@ int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float
 }
 
 int pt_session_create(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, pt_session **out) {
-    return guarded([&] { return session_create_impl(scene, width, height, row_begin, row_end, out); });
+    return guarded([&] { return ptc::session_create_on(scene, width, height, row_begin, row_end, nullptr, nullptr, nullptr, out); });
 }
 
 int pt_session_render(pt_session *session, const pt_render_params *params, pt_render_stats *stats) {
@@ -892,6 +987,7 @@ void pt_session_destroy(pt_session *s) {
         (void)hipStreamDestroy(s->stream);
     }
     if (s->d_band) (void)hipFree(s->d_band);
+    ptc::ctx_destroy(s->ctx);
     delete s;
 }
 

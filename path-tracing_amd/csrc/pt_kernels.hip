@@ -27,6 +27,7 @@
 // cannot reject a hit"; the verification build, -DPT_VERIFY_BRUTE, re-checks every segment against the all-triangles loop).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "pt_fastfp.hpp"
@@ -1493,22 +1494,25 @@ hipError_t launch_integrator(const RenderArgs &args0, hipStream_t stream) {
     }
     return hipSuccess;
 }
+hipError_t integrator_waves_per_cu(const RenderArgs &, int *waves) {
+    *waves = 24;
+    return hipSuccess;
+}
 #else
-hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
-    const int rows = args.row_end - args.row_begin;
-    if (rows <= 0 || args.width <= 0) return hipSuccess;
-    const unsigned grid = args.n_tiles * args.n_chunks;
+namespace {
+// Calls f(kernel) with the instantiation a launch with these arguments runs.
+template <class F>
+void with_instantiation(const RenderArgs &args, F &&f) {
     const bool big = args.n_tri > kBigSceneTriangles;
 #if defined(PT_PHASE_TIMERS) || defined(PT_VERIFY_BRUTE)
     const bool stats = true;
 #else
     const bool stats = args.stats != nullptr;
 #endif
-    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args); };
     auto pick = [&](auto sky, auto bg, auto st) {
         constexpr bool S = decltype(sky)::value, B = decltype(bg)::value, T = decltype(st)::value;
-        if (args.may_leave_envelope) go(integrate_kernel<S, B, T, true>);
-        else go(integrate_kernel<S, B, T, false>);
+        if (args.may_leave_envelope) f(integrate_kernel<S, B, T, true>, ((S * 2 + B) * 2 + T) * 2 + 1);
+        else f(integrate_kernel<S, B, T, false>, ((S * 2 + B) * 2 + T) * 2);
     };
     using Yes = std::true_type;
     using No = std::false_type;
@@ -1523,7 +1527,36 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
         else if (big) pick(No(), Yes(), No());
         else pick(No(), No(), No());
     }
+}
+}  // namespace
+
+hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
+    const int rows = args.row_end - args.row_begin;
+    if (rows <= 0 || args.width <= 0) return hipSuccess;
+    const unsigned grid = args.n_tiles * args.n_chunks;
+    with_instantiation(args, [&](auto kernel, int) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args); });
     return hipGetLastError();
+}
+
+// Waves (= workgroups: one wave each) of that instantiation one compute unit holds at a time, from the runtime's occupancy
+// calculation (registers, LDS, launch bounds): the scheduler's count of wave slots.  Asked once per instantiation and device.
+hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves) {
+    constexpr int kDevices = 16;
+    static std::atomic<int> cache[kDevices][16];   // 0 = not asked yet
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipError_t result = hipSuccess;
+    with_instantiation(args, [&](auto kernel, int id) {
+        int n = dev < kDevices ? cache[dev][id].load(std::memory_order_relaxed) : 0;
+        if (n == 0) {
+            result = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0);
+            if (result != hipSuccess || n <= 0) n = 0;
+            else if (dev < kDevices) cache[dev][id].store(n, std::memory_order_relaxed);
+        }
+        if (n > 0) *waves = n;
+    });
+    return result;
 }
 #endif
 

@@ -51,6 +51,8 @@ struct RenderArgs {
 };
 
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);
+// waves of the instantiation such a launch runs that one compute unit holds at a time (runtime occupancy query, cached)
+hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves);
 hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, const float *d_directions, int n_rays,
                              int32_t *d_hit_index, float *d_hit_t, hipStream_t stream);
 

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     assert declared == set(pt.ABI_SYMBOLS)
     for name in declared:
         assert getattr(pt.lib(), name) is not None
-    assert pt.lib().pt_abi_version() == 2 == pt.PT_ABI_VERSION
+    assert pt.lib().pt_abi_version() == 3 == pt.PT_ABI_VERSION
     assert not hasattr(pt.lib(), "pt_test_set_mutation")      # the test hooks exist only in the test builds
 
 
@@ -133,3 +133,48 @@ def test_cli_fails_loudly_without_gpu(models_dir, tmp_path):
     r = subprocess.run([exe, "--W", "8", "--H", "8", "-RPP", "1", "-MODEL_PATH", models_dir], cwd=tmp_path,
                        capture_output=True, text=True)
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_table_limits_are_refused_not_truncated(tmp_path):
+    """The kernels pack a slot into 24 bits of a (ray, slot) pair and a box-tree node's child base into 21 bits of
+    BvhNode::meta; a hierarchy beyond either must be refused (synthetic counts: no 16 M-triangle scene needed)."""
+    L = pt.lib()
+    assert L.pt_table_limits_check((1 << 24) - 1, (1 << 21) - 1, 8) == pt.PT_OK
+    assert L.pt_table_limits_check(1 << 24, 10, 3) == 7 and b"24 bits" in L.pt_last_error()          # PT_ERR_UNSUPPORTED
+    assert L.pt_table_limits_check(1000, 1 << 21, 3) == 7 and b"21 bits" in L.pt_last_error()
+    assert L.pt_table_limits_check(1000, 10, 9) == 7 and b"levels" in L.pt_last_error()
+    # what the builder produces for a scene of the size class the advisor worried about stays far inside: slots per triangle
+    # and nodes per triangle of the biggest scene of the suite
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_replicated_scene as M
+    d = str(tmp_path) + "/"
+    M.generate(os.path.join(ROOT, "models"), d, "x64.obj", 64)
+    s = pt.Scene.load_obj(d, "x64.obj", device=-1)
+    lay = s.cull_layout()
+    n_tri = s.counts()[0]
+    assert len(lay["slot_triangle"]) < 4 * n_tri and len(lay["bvh"]) < n_tri      # so 2^21 nodes are beyond the 2^23-triangle bound's reach only
+                                                                                    # for trees the check above refuses
+
+
+def test_rccl_loads_and_exports_what_the_gather_calls():
+    """pt_frame's gather uses RCCL directly (ncclCommInitAll, ncclGroupStart/End, ncclSend, ncclRecv); the library is opened
+    at run time.  On a box without a GPU it must still load and resolve."""
+    assert pt.rccl_version() >= 20000
+
+
+def test_clone_shares_the_host_side_and_frame_needs_a_device(models_dir):
+    s = pt.Scene.load_obj(models_dir, "Tor.obj", device=-1)
+    c = s.clone_to_device(-1)
+    assert c.counts() == s.counts() == (270, 5)
+    s.cull_layout()                                   # builds the hierarchy for eps 1e-4 once ...
+    built = s.timings()["hierarchy_build_s"]
+    assert built > 0
+    c.cull_layout()                                   # ... the copy finds it in the shared cache
+    assert c.timings()["hierarchy_build_s"] == built
+    s.close()                                         # either may go first
+    assert c.counts() == (270, 5)
+    if pt.device_count() == 0:
+        with pytest.raises(pt.PtError) as e:
+            pt.Frame(c, [0], 64, 64)
+        assert e.value.status == 4                    # PT_ERR_NO_DEVICE: no CPU fallback

@@ -10,9 +10,20 @@
 // one pass), so the time limit is checked at the reference's granularity -- before a pass starts (main.cpp:111-114) --
 // whatever -UPDATE is.
 //
+// Several GPUs: the reference splits the image's rows over its OpenMP threads inside the pass loop (main.cpp:115,132,141);
+// `-GPUS N` splits them over the first N devices of the node (or `-DEVICES 0,2,5`) through pt_frame_*: N row bands, every
+// pass slice enqueued on all devices before anything waits, the bands' accumulators gathered to the first device by one RCCL
+// group of sends / receives, then the unmodified resolve.  The image is bit-identical for any N.  On a box with fewer
+// devices `-REHEARSE 1` runs the N-band code path anyway, several bands per device, with device-to-device copies in place of
+// the collective -- and says so on stderr; without it such a request is refused.
+//
 // Extra flags (not in the reference): -OUT <file> writes only that file instead of the two reference outputs,
-// -DEVICE <n> selects the HIP device, -QUIET 1 drops the per-pass lines, -TIMING 1 prints one JSON line with the
-// seconds spent in each phase (HIP start-up, load, render, read-back, resolve, BMP write) on stderr.
+// -DEVICE <n> selects the HIP device (one GPU), -GPUS / -DEVICES / -REHEARSE as above, -QUIET 1 drops the per-pass lines,
+// -TIMING 1 prints one JSON line with the seconds spent in each phase (HIP start-up, load, render, read-back, resolve, BMP
+// write) on stderr, -BENCH_STEPS k [-BENCH_WARMUP w] times k whole frames (clear, all passes on all devices, gather, wait)
+// after w untimed ones and prints one JSON line on stdout instead of writing an image, -SELFCOLL 1 (test aid, one GPU)
+// routes the band through an RCCL send / receive to self, -FASTEXIT 1 leaves with _Exit once the files are written (skips the
+// runtime's teardown).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -37,6 +48,9 @@ struct Options {   // defaults: config.h:16-29
     int seed = 42, time_limit = 0;
     std::string out;
     int device = 0, quiet = 0, timing = 0;
+    int gpus = 0, rehearse = 0, selfcoll = 0, bench_steps = 0, bench_warmup = 1, fast_exit = 0;
+    std::string devices;
+    long long t0_ns = 0;   // -T0_NS: CLOCK_REALTIME of the parent just before it started this process (bench.py), for the start-up phase
 };
 
 long long now_ms() {
@@ -67,6 +81,14 @@ void parse(int argc, char **argv, Options &o) {   // pairs `flag value` from arg
         if (f == "-DEVICE") o.device = std::atoi(v);
         if (f == "-QUIET") o.quiet = std::atoi(v);
         if (f == "-TIMING") o.timing = std::atoi(v);
+        if (f == "-GPUS") o.gpus = std::atoi(v);
+        if (f == "-DEVICES") o.devices = v;
+        if (f == "-REHEARSE") o.rehearse = std::atoi(v);
+        if (f == "-SELFCOLL") o.selfcoll = std::atoi(v);
+        if (f == "-BENCH_STEPS") o.bench_steps = std::atoi(v);
+        if (f == "-BENCH_WARMUP") o.bench_warmup = std::atoi(v);
+        if (f == "-T0_NS") o.t0_ns = std::atoll(v);
+        if (f == "-FASTEXIT") o.fast_exit = std::atoi(v);
     }
 }
 
@@ -90,15 +112,81 @@ int main(int argc, char **argv) {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const clk::time_point t_begin = clk::now();
-    if (pt_device_count() < 1) {   // first HIP call: runtime start-up
+    double pre_main_s = 0;   // exec + dynamic linking, when the parent told us when it started us
+    if (o.t0_ns > 0) {
+        timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        pre_main_s = (static_cast<long long>(ts.tv_sec) * 1000000000LL + ts.tv_nsec - o.t0_ns) * 1e-9;
+    }
+    // The model is parsed before the first HIP call (host-only scene): nothing below depends on the device yet.
+    pt_scene *scene = nullptr;
+    if (pt_scene_load_obj(o.model_path.c_str(), o.model_name.c_str(), -1, &scene) != PT_OK) return die("pt_render");
+    if (!o.skybox.empty() && pt_scene_set_skybox_bmp(scene, o.skybox.c_str()) != PT_OK) return die("pt_render");   // scene.cpp:20-22
+    const clk::time_point t_parse = clk::now();
+    const int n_dev = pt_device_count();   // first HIP call: runtime start-up
+    if (n_dev < 1) {
         std::cerr << "pt_render: no HIP device (the integrator has no CPU fallback)" << std::endl;
         return 1;
     }
     const clk::time_point t_hip = clk::now();
-    pt_scene *scene = nullptr;
-    if (pt_scene_load_obj(o.model_path.c_str(), o.model_name.c_str(), o.device, &scene) != PT_OK) return die("pt_render");
-    if (!o.skybox.empty() && pt_scene_set_skybox_bmp(scene, o.skybox.c_str()) != PT_OK) return die("pt_render");   // scene.cpp:20-22
+
+    // Row bands -> devices (main.cpp:115,132,141: the reference's split of the rows over its threads).
+    std::vector<int32_t> devices;
+    if (!o.devices.empty()) {
+        for (size_t at = 0; at <= o.devices.size();) {
+            const size_t comma = std::min(o.devices.find(',', at), o.devices.size());
+            devices.push_back(std::atoi(o.devices.substr(at, comma - at).c_str()));
+            at = comma + 1;
+        }
+    } else if (o.gpus > 0) {
+        for (int b = 0; b < o.gpus; ++b) devices.push_back(o.rehearse ? b % n_dev : b);
+    } else {
+        devices.push_back(o.device);
+    }
+    uint32_t flags = 0;
+    if (o.rehearse) flags |= PT_FRAME_REHEARSE;
+    if (o.selfcoll) flags |= PT_FRAME_SELF_COLLECTIVE;
+    pt_frame *frame = nullptr;
+    if (pt_frame_create(scene, devices.data(), static_cast<int32_t>(devices.size()), o.width, o.height, flags, &frame) != PT_OK)
+        return die("pt_render");
+    int32_t transport = 0;
+    pt_frame_info(frame, nullptr, nullptr, nullptr, &transport);
+    const char *transport_name = transport == PT_FRAME_TRANSPORT_RCCL ? "rccl" : transport == PT_FRAME_TRANSPORT_DEVICE_COPIES ? "device_copies" : "none";
+    if (transport == PT_FRAME_TRANSPORT_DEVICE_COPIES)
+        std::cerr << "pt_render: REHEARSAL -- " << devices.size() << " row bands on " << n_dev << " device(s); the gather is device-to-device "
+                     "copies, not the RCCL collective" << std::endl;
     const clk::time_point t_load = clk::now();
+
+    pt_render_params rp;
+    std::memset(&rp, 0, sizeof rp);
+    rp.width = o.width; rp.height = o.height; rp.row_begin = 0; rp.row_end = o.height;
+    rp.max_ray_reflections = o.max_ray_reflections;
+    rp.eps = o.eps; rp.error = o.error; rp.seed = seed;
+
+    if (o.bench_steps > 0) {
+        // k whole frames: zero the accumulators, every pass on every device, the gather, wait for all of it
+        auto one_frame = [&]() {
+            rp.pass_begin = 0;
+            rp.pass_count = o.rays_per_pixel;
+            return pt_frame_clear(frame) == PT_OK && pt_frame_render(frame, &rp, nullptr) == PT_OK && pt_frame_gather(frame) == PT_OK;
+        };
+        for (int i = 0; i < std::max(o.bench_warmup, 0); ++i)
+            if (!one_frame()) return die("pt_render");
+        if (pt_frame_wait(frame) != PT_OK) return die("pt_render");
+        const clk::time_point a = clk::now();
+        for (int i = 0; i < o.bench_steps; ++i)
+            if (!one_frame()) return die("pt_render");
+        if (pt_frame_wait(frame) != PT_OK) return die("pt_render");
+        const double dt = secs(a, clk::now());
+        const double samples = static_cast<double>(o.width) * o.height * o.rays_per_pixel * o.bench_steps;
+        std::printf("{\"cxx_frame\": true, \"value\": %.3f, \"unit\": \"Msamples/s\", \"ms_per_step\": %.4f, \"steps\": %d, \"warmup\": %d, "
+                    "\"bands\": %zu, \"devices_visible\": %d, \"transport\": \"%s\", \"width\": %d, \"height\": %d, \"spp\": %d, \"mrr\": %d, \"error\": %g}\n",
+                    samples / dt / 1e6, dt / o.bench_steps * 1e3, o.bench_steps, o.bench_warmup, devices.size(), n_dev, transport_name, o.width, o.height,
+                    o.rays_per_pixel, o.max_ray_reflections, static_cast<double>(o.error));
+        pt_frame_destroy(frame);
+        pt_scene_destroy(scene);
+        return 0;
+    }
 
     const size_t px = static_cast<size_t>(o.width) * o.height;
     // page-locked accumulators: the read-back then runs at PCIe speed without staging copies
@@ -113,17 +201,11 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> bgr(3 * px);
     float disp[3] = {0, INFINITY, 0};
     double read_s = 0, preview_s = 0;
+    const clk::time_point t_alloc = clk::now();
 
-    pt_session *session = nullptr;
-    if (pt_session_create(scene, o.width, o.height, 0, o.height, &session) != PT_OK) return die("pt_render");
-    pt_render_params rp;
-    std::memset(&rp, 0, sizeof rp);
-    rp.width = o.width; rp.height = o.height; rp.row_begin = 0; rp.row_end = o.height;
-    rp.max_ray_reflections = o.max_ray_reflections;
-    rp.eps = o.eps; rp.error = o.error; rp.seed = seed;
-    auto read_back = [&]() {
+    auto read_back = [&]() {   // gathers the bands (one collective) if any changed, waits, copies the frame out
         const clk::time_point a = clk::now();
-        const int rc = pt_session_read(session, sum, sum2, count);
+        const int rc = pt_frame_read(frame, sum, sum2, count);
         read_s += secs(a, clk::now());
         return rc;
     };
@@ -155,8 +237,8 @@ int main(int argc, char **argv) {
         rp.pass_count = slice_end - rays_count;
         pt_render_stats st;
         const clk::time_point a = clk::now();
-        if (pt_session_render(session, &rp, o.time_limit != 0 ? &st : nullptr) != PT_OK) return die("pt_render");
-        if (o.time_limit != 0) ms_per_pass = 1e3 * secs(a, clk::now()) / rp.pass_count;   // the call waited for the kernel
+        if (pt_frame_render(frame, &rp, o.time_limit != 0 ? &st : nullptr) != PT_OK) return die("pt_render");
+        if (o.time_limit != 0) ms_per_pass = 1e3 * secs(a, clk::now()) / rp.pass_count;   // the call waited for the kernels
         for (int p = rays_count; p < slice_end; ++p) {
             if (o.update != 0 && p % o.update == 0) {
                 const clk::time_point b = clk::now();
@@ -171,15 +253,17 @@ int main(int argc, char **argv) {
         }
         rays_count = slice_end;
     }
-    if (pt_session_wait(session) != PT_OK) return die("pt_render");   // the last slice (and, in a fresh process, the
-    const clk::time_point t_kernels = clk::now();                      // one-time load of the kernels' code object)
+    const clk::time_point t_enqueued = clk::now();
+    if (pt_frame_gather(frame) != PT_OK) return die("pt_render");   // the frame's one collective (nothing to do for one band)
+    if (pt_frame_wait(frame) != PT_OK) return die("pt_render");     // the last slice (and, in a fresh process, the
+    const clk::time_point t_kernels = clk::now();                    // one-time load of the kernels' code object)
     if (read_back() != PT_OK) return die("pt_render");
     const clk::time_point t_render = clk::now();
 
     if (o.gauss || o.median) {   // main.cpp:187-201: filters act on the tonemapped float image, then set_pixel
         std::vector<float> rgb(3 * px);
         pt_resolve_float(o.width, o.height, sum, sum2, count, o.gamma_correction, rgb.data(), disp);
-        if (pt_post_filter_host(o.device, o.width, o.height, rgb.data(), o.gauss, o.median) != PT_OK) return die("pt_render");
+        if (pt_post_filter_host(devices[0], o.width, o.height, rgb.data(), o.gauss, o.median) != PT_OK) return die("pt_render");
         pt_quantize(o.width, o.height, rgb.data(), count, bgr.data());
     } else {
         pt_resolve(o.width, o.height, sum, sum2, count, o.gamma_correction, bgr.data(), disp);
@@ -203,12 +287,23 @@ int main(int argc, char **argv) {
     std::cout << name << std::endl;
     if (o.timing) {
         const clk::time_point t_end = clk::now();
-        std::fprintf(stderr, "{\"hip_startup_s\": %.4f, \"load_s\": %.4f, \"render_s\": %.4f, \"read_back_s\": %.4f, \"previews_s\": %.4f, "
-                             "\"resolve_s\": %.4f, \"bmp_write_s\": %.4f, \"total_s\": %.4f}\n",
-                     secs(t_begin, t_hip), secs(t_hip, t_load), secs(t_load, t_kernels) - preview_s, secs(t_kernels, t_render), preview_s,
-                     secs(t_render, t_resolve), secs(t_resolve, t_end), secs(t_begin, t_end));
+        double host_s[2] = {0, 0};
+        pt_scene_timings(scene, host_s);
+        std::fprintf(stderr, "{\"pre_main_s\": %.4f, \"parse_s\": %.4f, \"hip_startup_s\": %.4f, \"frame_setup_s\": %.4f, \"host_alloc_s\": %.4f, "
+                             "\"enqueue_s\": %.4f, \"hierarchy_build_s\": %.4f, \"kernels_wait_s\": %.4f, \"read_back_s\": %.4f, \"previews_s\": %.4f, "
+                             "\"resolve_s\": %.4f, \"bmp_write_s\": %.4f, \"main_s\": %.4f, \"bands\": %zu, \"transport\": \"%s\"}\n",
+                     pre_main_s, secs(t_begin, t_parse), secs(t_parse, t_hip), secs(t_hip, t_load), secs(t_load, t_alloc),
+                     secs(t_alloc, t_enqueued) - preview_s, host_s[1], secs(t_enqueued, t_kernels), secs(t_kernels, t_render), preview_s,
+                     secs(t_render, t_resolve), secs(t_resolve, t_end), secs(t_begin, t_end), devices.size(), transport_name);
     }
-    pt_session_destroy(session);
+    if (o.fast_exit) {
+        // Every file is written and closed; tearing the HIP runtime down (code objects, device heap, RCCL) is all that a normal
+        // exit would add.
+        std::cout.flush();
+        std::cerr.flush();
+        std::_Exit(rc);
+    }
+    pt_frame_destroy(frame);
     pt_scene_destroy(scene);
     return rc;
 }
