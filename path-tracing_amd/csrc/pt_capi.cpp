@@ -1021,6 +1021,7 @@ int pt_test_set_mutation(const char *family, double value) {
     else if (f == "box_err") m.box_err = value;
     else if (f == "no_absorb") m.no_absorb = value != 0;
     else if (f == "no_last_segment_filter") m.no_last_segment_filter = value != 0;
+    else if (f == "emis_drop") m.emis_drop = value != 0;
     else if (f == "order_mode") m.order_mode = static_cast<int>(value);
     else if (f == "bvh_fill") m.bvh_fill = value;
     else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);

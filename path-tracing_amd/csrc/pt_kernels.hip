@@ -1103,6 +1103,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
 
     const int mrr = a.mrr;
     const float eps = a.eps;
+#ifdef PT_VERIFY_SHIPPED
+    uint32_t v_checked = 0, v_bad = 0;   // wave-uniform
+#endif
 
     for (int pass = pass_first; pass < pass_last; ++pass) {
         // Adaptive skip, main.cpp:118-125.
@@ -1167,6 +1170,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
             constexpr bool kLastSegmentFilter = !STATS && !SKY && !BIG;   // (big scenes: the flag's scalar registers cost more than it saves)
             bool emis_phase = false;
             if constexpr (kLastSegmentFilter) emis_phase = a.last_segment_filter != 0u && __all(!valid || depth + 1 >= mrr);
+#ifdef PT_VERIFY_SHIPPED
+            bool filtered_last = emis_phase;   // wave-uniform: this segment's search only has to find emitters
+#endif
             if constexpr (BIG && !STATS && !SKY) {
                 // Big scenes: the same idea without a second search.  The table builder keeps a big scene's emitters in the
                 // large class (pt_scene.cpp), so the conservative test of those records alone says which rays of the last
@@ -1191,6 +1197,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                         bool can_reach = (m & a.emis_large_w0) != 0u;
                         if constexpr (ENV) can_reach = can_reach || !inside;   // (outside the margins' envelope nothing is culled)
                         searched = valid && can_reach;
+#ifdef PT_VERIFY_SHIPPED
+                        filtered_last = true;
+#endif
                     }
                 }
             }
@@ -1203,6 +1212,36 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                 if (!__any(searched)) break;
             }
             if (!searched) hit = -1;   // (a ray of the last segment that met no emitter ends like a miss, contributing nothing)
+#ifdef PT_VERIFY_SHIPPED
+            // Verification of the path that SHIPS (libpt_verify_shipped.so, never the product): this is the statistics-free
+            // instantiation with the emitter-first last segment and the big scenes' can-reach filter compiled in.  Every segment's
+            // result is compared with Scene::TraceRay's loop as written (scene.cpp:116-120) for the lane's own ray: the same
+            // (distance bits, triangle index) -- except that a FILTERED last segment may report a miss where the reference hits
+            // something, if and only if that something has no emissive lobe (nothing else of a last segment is ever looked at:
+            // Ray::IsValid ray.h:52-54, material.h:67-80).
+            {
+                const unsigned long long brute = brute_force_key(a, q, eps);
+                const unsigned long long mine = hit < 0 ? ~0ull : ((static_cast<unsigned long long>(ordered_bits(best)) << 32) | static_cast<uint32_t>(hit));
+                bool ok = brute == mine;
+                if (!ok && filtered_last && mine == ~0ull) {
+                    bool emissive = false;
+                    if (brute != ~0ull) {
+                        const MatRec m = a.mats[a.exact[static_cast<uint32_t>(brute)].material];
+                        emissive = (m.n_lobes >= 1 && m.kind0 == 0) || (m.n_lobes >= 2 && m.kind1 == 0);
+                    }
+                    ok = !emissive;
+                }
+                v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid)));
+                v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid && !ok)));
+                if (valid && !ok && a.stats) {   // one example for the host to print (any of them)
+                    a.stats[11] = brute;
+                    a.stats[12] = mine;
+                    a.stats[13] = (static_cast<unsigned long long>(__float_as_uint(q.ox)) << 32) | __float_as_uint(q.oy);
+                    a.stats[14] = (static_cast<unsigned long long>(__float_as_uint(q.oz)) << 32) | __float_as_uint(q.dx);
+                    a.stats[15] = (static_cast<unsigned long long>(__float_as_uint(q.dy)) << 32) | __float_as_uint(q.dz);
+                }
+            }
+#endif
 
             // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
             if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
@@ -1373,6 +1412,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler (guide, G16)
         if (lane == 0) __hip_atomic_store(&a.sched[1 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef PT_VERIFY_SHIPPED
+    if (a.stats && lane == 0) {
+        atomicAdd(&a.stats[9], static_cast<unsigned long long>(v_checked));
+        if (v_bad) atomicAdd(&a.stats[10], static_cast<unsigned long long>(v_bad));
+    }
+#endif
     if constexpr (STATS) if (a.stats && lane == 0) {
         atomicAdd(&a.stats[0], static_cast<unsigned long long>(n_traced));
         atomicAdd(&a.stats[1], static_cast<unsigned long long>(n_segments));
@@ -1506,6 +1551,8 @@ void with_instantiation(const RenderArgs &args, F &&f) {
     const bool big = args.n_tri > kBigSceneTriangles;
 #if defined(PT_PHASE_TIMERS) || defined(PT_VERIFY_BRUTE)
     const bool stats = true;
+#elif defined(PT_VERIFY_SHIPPED)
+    const bool stats = false;   // the instantiations a caller without pt_render_stats gets; args.stats only receives the verdict
 #else
     const bool stats = args.stats != nullptr;
 #endif

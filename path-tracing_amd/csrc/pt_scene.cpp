@@ -1176,6 +1176,10 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         }
     }
     if (out.clusters.size() > 32) out.emis_clusters = 0xFFFFFFFFu;   // (small scenes have at most 10 clusters)
+#ifdef PT_TEST_HOOKS
+    // negative control of the shipped-path verification: forget one emitter of the large class
+    if (g_cull_mutation.emis_drop && out.emis_large_w0 != 0xFFFFFFFFu) out.emis_large_w0 &= out.emis_large_w0 - 1u;
+#endif
     out.emis_bvh = false;
     if (!out.bvh.empty())
         for (uint32_t k = 0; k < static_cast<uint32_t>(n_small_slots); ++k) out.emis_bvh = out.emis_bvh || emits(k);

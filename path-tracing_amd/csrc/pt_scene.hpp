@@ -138,6 +138,7 @@ struct CullTables {
 struct CullMutation {
     double sphere_r2 = 1, m0 = 1, k12 = 1, a_max = 1, quad_slack = 1, box = 1, box_err = 1;
     int no_absorb = 0;
+    int emis_drop = 0;                // table builder: 1 = the lowest emitter bit of the large class is cleared (a WRONG table: negative control)
     int no_last_segment_filter = 0;   // integrator: 1 = a path's last segment searches all triangles like every other segment
     double bvh_fill = 0.5;    // box tree: target fill of a node's children (builder tuning)
     int order_mode = 0;   // small-scene clusters: 0 = cheaper of (cells, patches), 1 = as filed, 2 = cells, 3 = patches

@@ -55,6 +55,31 @@ def test_bench_emits_one_valid_json_line():
     # configs[3] as written (3840 x 2160 x 256 spp), reported beside the headline value
     c3 = j["configs3_strong"]
     assert c3["scaling"] == "strong" and c3["value"] > 100.0
+    # what the roofline fraction means: issued instructions, the part of their lanes that was on, the reference's own arithmetic
+    assert "x 8 spp" in j["metric"]
+    assert 0 < rf["useful_fraction"] < rf["frac_active_lanes"] < rf["frac"]
+    assert abs(rf["frac_active_lanes"] - rf["frac"] * rf["valu_active_lane_fraction"]) < 1e-9
+    # the accuracy sample ran the instantiation the timed launches run
+    assert "false,false,false,false" in ac["gpu_instantiation"]
+    # BASELINE configs[1] on fixed work, the reference-default adaptive run, configs[4] with its own counters: driver-timed
+    assert j["configs1_64spp"]["value"] > 100.0 and "64 spp" in j["configs1_64spp"]["workload"]
+    ad = j["adaptive_default"]
+    assert 0 < ad["samples_traced"] < ad["nominal_samples"] == 1920 * 1080 * 256
+    assert ad["value_traced"] < ad["value_nominal"] == ad["value"] and ad["value"] > j["configs1_64spp"]["value"]
+    rep = j["configs4_replica"]
+    assert rep["x64"]["triangles"] == 16398 and rep["x195"]["triangles"] == 49934
+    assert rep["x64"]["value"] > rep["x195"]["value"] > 100.0
+    rb = rep["x64"]["roofline"]
+    assert rb["kernel"] == "pt::integrate_kernel<false,true,false,false>" and rb["achieved"] is not None, rb["counters_source"]
+    assert 0 < rb["useful_fraction"] < rb["frac_active_lanes"] < rb["frac"] <= 1.0
+    assert 0.3 < rb["l1_hit_rate"] < 1.0 and rb["issue"]["instructions_per_wave_segment"] > 500
+    assert rep["x64"]["node_rounds_per_wave_segment"] > 1
+    # the C++ host alone on the same frame (pt_render -GPUS 1 -BENCH_STEPS): the same rate (a 2.8 ms frame at 8 spp: loose here)
+    cx = j["cxx_frame"]["weak"]
+    assert cx["cxx_frame"] and cx["bands"] == 1 and cx["transport"] == "none" and abs(cx["over_torch_leg"] - 1) < 0.15
+    # end to end: the phases account for the wall time
+    ee = j["end_to_end"]
+    assert abs(ee["seconds"] - ee["phases"]["pre_main_s"] - ee["phases"]["main_s"] - ee["exit_and_wait_s"]) < 1e-6
 
 
 def test_two_rank_rehearsal_frame_equals_single_process(tmp_path):
@@ -86,6 +111,8 @@ def test_self_launch_two_ranks_and_too_many_gpus(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["config"]["parallelism"] == "rowband2"
+    cx = j["cxx_frame"]["weak"]       # the C++ host's two-band frame next to the two-rank torch leg (rehearsed: device copies)
+    assert cx["bands"] == 2 and cx["transport"] == "device_copies" and cx["value"] > 100.0
     import torch
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, cwd=ROOT,

@@ -1,0 +1,90 @@
+"""Every segment of a frame, checked on the device, for the kernel instantiations that SHIP.
+
+libpt_verify.so (test_gpu_verify.py) forces the statistics instantiations, which run the full search on every segment; the
+launches a caller without pt_render_stats gets are different code: a path's last segment searches the emitters first and
+everything only for rays that hit one (small scenes), or is searched only for rays that can reach an emitter at all (big
+scenes).  libpt_verify_shipped.so (-DPT_VERIFY_SHIPPED) is the product library whose STATISTICS-FREE instantiations compare
+every segment with Scene::TraceRay's all-triangles loop (scene.cpp:116-120): the same (distance bits, triangle index) --
+except that a filtered last segment may report a miss where the reference hits a triangle WITHOUT an emissive lobe, the only
+thing of a last segment the reference ever looks at (ray.h:52-54, material.h:67-80).
+"""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pt = importlib.import_module("path-tracing_amd")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "path-tracing_amd", "lib", "libpt_verify_shipped.so")
+
+
+@pytest.fixture(scope="module")
+def vlib():
+    assert pt.device_count() >= 1, "no HIP device: the integrator has no CPU fallback"
+    L = pt.load_library(LIB)
+    L.pt_test_set_mutation(b"reset", 0.0)
+    yield L
+    L.pt_test_set_mutation(b"reset", 0.0)
+
+
+def _digest(s, s2, c):
+    return hashlib.sha256(s.tobytes() + s2.tobytes() + c.tobytes()).hexdigest()
+
+
+def _replica(tmp, instances):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_replicated_scene as M
+    d = str(tmp) + "/"
+    name = f"TorX{instances}.obj"
+    M.generate(os.path.join(ROOT, "models"), d, name, instances)
+    return d, name
+
+
+def _check(vlib, d, name, W, H, spp, mrr, **kw):
+    v = pt.Scene.load_obj(d, name, device=0, library=vlib)
+    s, s2, c, st = v.render_host(W, H, spp, mrr, **kw)                   # statistics asked for: they carry only the verdict here
+    g = pt.Scene.load_obj(d, name, device=0)
+    ref = g.render_host(W, H, spp, mrr, **kw)                           # shipped library, statistics instantiation: the segment count
+    q = g.render_host(W, H, spp, mrr, want_stats=False, **kw)           # shipped library, the instantiation under test
+    assert st["segments"] == 0 and st["wave_segments"] == 0             # it really was the statistics-free instantiation
+    assert st["verify_checked"] == ref[3]["segments"] > 0
+    assert _digest(s, s2, c) == _digest(*q[:3]) == _digest(*ref[:3])    # and the verified frame is the shipped frame
+    return st
+
+
+def test_every_segment_of_config1_on_the_shipped_instantiation(models_dir, vlib):
+    """BASELINE configs[1], the whole frame: about 1.05e9 segments, one eighth of them filtered last segments."""
+    st = _check(vlib, models_dir, "Tor.obj", 1920, 1080, 64, 8, error=-1.0)
+    assert st["verify_checked"] > 7.5 * 1920 * 1080 * 64 and st["verify_mismatches"] == 0
+
+
+@pytest.mark.parametrize("mrr", [1, 2, 3])
+def test_short_paths_and_adaptive_sampling(models_dir, vlib, mrr):
+    """-MRR 1: every segment is a last segment (only camera rays that see the light contribute)."""
+    st = _check(vlib, models_dir, "Tor.obj", 640, 360, 24, mrr, error=0.001)
+    assert st["verify_mismatches"] == 0
+
+
+def test_every_segment_of_the_x64_replica_on_the_shipped_instantiation(tmp_path, vlib):
+    """BASELINE configs[4] geometry at 1080p x 4 spp: the big-scene kernel with its can-reach filter on last segments."""
+    d, name = _replica(tmp_path, 64)
+    st = _check(vlib, d, name, 1920, 1080, 4, 8, error=-1.0)
+    assert st["verify_checked"] > 7 * 1920 * 1080 * 4 and st["verify_mismatches"] == 0
+
+
+@pytest.mark.parametrize("scene", ["tor", "x9"])
+def test_the_check_notices_a_forgotten_emitter(tmp_path, models_dir, vlib, scene):
+    """Negative control: the table builder is told to forget one emitter of the large class (test hook emis_drop); the
+    last-segment filters then drop real contributions, and the comparison must count them."""
+    d, name = (models_dir, "Tor.obj") if scene == "tor" else _replica(tmp_path, 9)
+    vlib.pt_test_set_mutation(b"emis_drop", 1.0)
+    try:
+        v = pt.Scene.load_obj(d, name, device=0, library=vlib)
+        st = v.render_host(640, 360, 16, 8, error=-1.0)[3]
+    finally:
+        vlib.pt_test_set_mutation(b"reset", 0.0)
+    assert st["verify_checked"] > 0 and st["verify_mismatches"] > 100, st

@@ -84,8 +84,8 @@ def main():
     ks = max(glob.glob(os.path.join(G, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(ks, os.path.join(P, f"{t}_kernel_stats.csv"))
     out = {}
-    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (bench.py --pmc-child, timed kernel integrate_kernel<false,false,false,false>)", True),
-                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x8spp (tools/c5_probe.py, integrate_kernel<false,true,true,false>)", False)):
+    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,false,false,false>)", True),
+                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,true,false,false>)", True)):
         m = detail(os.path.join(G, name), timed)
         if m:
             out[label] = m

@@ -26,11 +26,14 @@ GROUPS_=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVES"
          "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU"
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum")
+python3 "$R/tools/make_replicated_scene.py" --instances 64 --out-dir "$O/x64scene" > /dev/null
+PTR="$R/path-tracing_amd/bin/pt_render"
+FRAME="--W 1920 --H 1080 -RPP 256 -MRR 8 -ERR -1 -SEED 42 -BENCH_STEPS 1 -BENCH_WARMUP 1"
 i=0
 for g in "${GROUPS_[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $g -d "$O/pmc_tor/p$i" -o p --output-format csv -- python3 "$R/bench.py" --pmc-child --spp 256 --steps 1 --warmup 1 > "$O/pmc_tor_p$i.log" 2>&1
-  rocprofv3 --pmc $g -d "$O/pmc_x64/p$i" -o p --output-format csv -- python3 "$R/tools/c5_probe.py" 64 > "$O/pmc_x64_p$i.log" 2>&1
+  rocprofv3 --pmc $g -d "$O/pmc_tor/p$i" -o p --output-format csv -- "$PTR" $FRAME -MODEL_PATH "$R/models/" > "$O/pmc_tor_p$i.log" 2>&1
+  rocprofv3 --pmc $g -d "$O/pmc_x64/p$i" -o p --output-format csv -- "$PTR" $FRAME -MODEL_PATH "$O/x64scene/" -MODEL_NAME TorX64.obj > "$O/pmc_x64_p$i.log" 2>&1
 done
 echo "pmc detail done"
 PT_HIP_LIB=$R/path-tracing_amd/lib/libpt_phase.so python3 "$R/tools/tor_probe.py" > "$O/phase_tor.log" 2>&1
