@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "pt_filters.hpp"
 
@@ -197,6 +198,7 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.clusters = scene->cull.clusters;
     a.spheres = scene->cull.spheres;
     a.bary = scene->cull.bary;
+    a.n_bary = static_cast<uint32_t>(t.bary.size());
     a.bary_all = scene->cull.bary_all;
     a.a_max_all = ca.a_max; a.m0_all = ca.m0; a.t_guard_all = ca.t_guard;
     a.exact = scene->d_exact;
@@ -763,79 +765,107 @@ static int scene_cull_layout_impl(pt_scene *scene, float eps, int32_t *counts, i
     return PT_OK;
 }
 
-int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
-               uint8_t *bgr, float *dispersion) {
-    if (width <= 0 || height <= 0 || !sum || !sum2 || !count || !bgr)
-        return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
-    float max_d = 0.0f, min_d = INFINITY, avg_d = 0.0f;
-    std::memset(bgr, 0, static_cast<size_t>(width) * height * 3);   // image.clear(), main.cpp:106
-    for (int y = 0; y < height; ++y) {
+}  // extern "C"
+
+// main.cpp:162-185 for the rows [y0, y1): per-pixel variance estimate d (written to contrib: d, or 1 for a pixel without samples,
+// main.cpp:165-168), running max / min of d in row order, and the tonemapped pixel through `put`.
+template <class Put>
+static void resolve_rows(int32_t width, int y0, int y1, const float *sum, const float *sum2, const int32_t *count, float gamma,
+                         float *contrib, float &max_d, float &min_d, Put &&put) {
+    for (int y = y0; y < y1; ++y) {
         for (int x = 0; x < width; ++x) {
             const size_t p = static_cast<size_t>(y) * width + x;
             if (!count[p]) {   // main.cpp:165-168
-                avg_d += 1;
+                contrib[p] = 1.0f;
+                put(p, nullptr);
                 continue;
             }
             const float n = static_cast<float>(count[p]);
-            float d = 0.0f, c[3];
-            float dd[3];
+            float c[3], dd[3];
             for (int k = 0; k < 3; ++k) {
                 const float mean = sum[3 * p + k] / n;
                 dd[k] = sum2[3 * p + k] / n - mean * mean;
                 c[k] = std::pow(sum[3 * p + k] / n, gamma) * 255.0f;   // main.cpp:179-182
             }
-            d = dd[0] + dd[1] + dd[2];
+            const float d = dd[0] + dd[1] + dd[2];
             if (d > max_d) max_d = d;
             if (d < min_d) min_d = d;
-            avg_d += d;
-            // set_pixel(x, y, float, float, float): float -> unsigned char (bitmap_image.hpp:194-206)
-            bgr[3 * p + 0] = static_cast<uint8_t>(static_cast<int>(c[2]));
-            bgr[3 * p + 1] = static_cast<uint8_t>(static_cast<int>(c[1]));
-            bgr[3 * p + 2] = static_cast<uint8_t>(static_cast<int>(c[0]));
+            contrib[p] = d;
+            put(p, c);
         }
     }
+}
+
+// The resolve is the reference's, value for value; only its schedule differs: bands of rows on the host's cores (powf per
+// channel is 20 ms of one core at 1080p), then what depends on the pixel ORDER in order -- the bands' max / min combined first
+// to last with the reference's own strict comparisons (ties, signed zeros: the first one in pixel order stays), and the float
+// sum of the per-pixel terms as one sequential pass.
+template <class Put>
+static void resolve_all(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
+                        float *dispersion, Put &&put) {
+    const size_t n_px = static_cast<size_t>(width) * height;
+    std::vector<float> contrib(n_px);
+    unsigned n_thr = n_px >= (1u << 18) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    n_thr = std::min<unsigned>(n_thr, static_cast<unsigned>(height));
+    std::vector<float> mx(n_thr, 0.0f), mn(n_thr, INFINITY);
+    auto band = [&](unsigned t) {
+        const int y0 = static_cast<int>(static_cast<long long>(height) * t / n_thr), y1 = static_cast<int>(static_cast<long long>(height) * (t + 1) / n_thr);
+        resolve_rows(width, y0, y1, sum, sum2, count, gamma, contrib.data(), mx[t], mn[t], put);
+    };
+    if (n_thr == 1) {
+        band(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(band, t);
+        band(0);
+        for (auto &t : th) t.join();
+    }
+    float max_d = 0.0f, min_d = INFINITY, avg_d = 0.0f;
+    for (unsigned t = 0; t < n_thr; ++t) {
+        if (mx[t] > max_d) max_d = mx[t];
+        if (mn[t] < min_d) min_d = mn[t];
+    }
+    for (size_t p = 0; p < n_px; ++p) avg_d += contrib[p];
     avg_d /= width * height;
     if (dispersion) {
         dispersion[0] = max_d;
         dispersion[1] = min_d;
         dispersion[2] = avg_d;
     }
-    return PT_OK;
+}
+
+extern "C" {
+
+int pt_resolve(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
+               uint8_t *bgr, float *dispersion) {
+    if (width <= 0 || height <= 0 || !sum || !sum2 || !count || !bgr)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
+    return guarded([&] {
+        resolve_all(width, height, sum, sum2, count, gamma, dispersion, [bgr](size_t p, const float *c) {
+            if (!c) {   // image.clear(), main.cpp:106: pixels without samples stay black
+                bgr[3 * p + 0] = bgr[3 * p + 1] = bgr[3 * p + 2] = 0;
+                return;
+            }
+            // set_pixel(x, y, float, float, float): float -> unsigned char (bitmap_image.hpp:194-206)
+            bgr[3 * p + 0] = static_cast<uint8_t>(static_cast<int>(c[2]));
+            bgr[3 * p + 1] = static_cast<uint8_t>(static_cast<int>(c[1]));
+            bgr[3 * p + 2] = static_cast<uint8_t>(static_cast<int>(c[0]));
+        });
+        return static_cast<int>(PT_OK);
+    });
 }
 
 int pt_resolve_float(int32_t width, int32_t height, const float *sum, const float *sum2, const int32_t *count, float gamma,
                      float *rgb, float *dispersion) {
     if (width <= 0 || height <= 0 || !sum || !sum2 || !count || !rgb)
         return fail(PT_ERR_INVALID_ARGUMENT, "null buffer or empty image");
-    float max_d = 0.0f, min_d = INFINITY, avg_d = 0.0f;
-    for (int y = 0; y < height; ++y) {
-        for (int x = 0; x < width; ++x) {
-            const size_t p = static_cast<size_t>(y) * width + x;
-            for (int k = 0; k < 3; ++k) rgb[3 * p + k] = sum[3 * p + k];   // color_map keeps its raw sums where nothing was counted
-            if (!count[p]) {
-                avg_d += 1;
-                continue;
-            }
-            const float n = static_cast<float>(count[p]);
-            float dd[3];
-            for (int k = 0; k < 3; ++k) {
-                const float mean = sum[3 * p + k] / n;
-                dd[k] = sum2[3 * p + k] / n - mean * mean;
-                rgb[3 * p + k] = std::pow(sum[3 * p + k] / n, gamma) * 255.0f;
-            }
-            const float d = dd[0] + dd[1] + dd[2];
-            if (d > max_d) max_d = d;
-            if (d < min_d) min_d = d;
-            avg_d += d;
-        }
-    }
-    avg_d /= width * height;
-    if (dispersion) {
-        dispersion[0] = max_d;
-        dispersion[1] = min_d;
-        dispersion[2] = avg_d;
-    }
-    return PT_OK;
+    return guarded([&] {
+        resolve_all(width, height, sum, sum2, count, gamma, dispersion, [rgb, sum](size_t p, const float *c) {
+            // color_map keeps its raw sums where nothing was counted
+            for (int k = 0; k < 3; ++k) rgb[3 * p + k] = c ? c[k] : sum[3 * p + k];
+        });
+        return static_cast<int>(PT_OK);
+    });
 }
 
 static int post_filter_host_impl(int device, int32_t width, int32_t height, float *rgb, int32_t gauss, int32_t median) {

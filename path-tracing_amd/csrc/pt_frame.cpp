@@ -109,7 +109,7 @@ struct pt_frame {
     size_t plane_floats = 0;
     std::vector<FrameXfer> xfers;
     std::vector<ncclComm_t> comms;         // RCCL transport: one communicator per distinct device, rank = index
-    hipStream_t gather_stream = nullptr;   // root device: the receives of the gather
+    hipStream_t gather_stream = nullptr;   // root device, RCCL transport only: the receives of the gather
     bool dirty = false;                    // a band was rendered or cleared since the last gather
     size_t n_px() const { return static_cast<size_t>(width) * height; }
     float *root_sum() const { return d_frame; }
@@ -179,7 +179,6 @@ int frame_create_impl(const pt_scene *scene, const int32_t *devices, int32_t n_b
     const size_t bytes = (2 * f->plane_floats + n) * sizeof(float) + 256;
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&f->d_frame), bytes));
     PT_HIP_TRY(hipMemset(f->d_frame, 0, bytes));
-    PT_HIP_TRY(hipStreamCreateWithFlags(&f->gather_stream, hipStreamNonBlocking));
     // sessions.  Band 0 (the root's) renders into the frame planes themselves; with the RCCL transport every other band is on
     // another device and has its own buffer; a rehearsal gives EVERY other band its own buffer, also on the root device, so
     // that the N-band gather really moves N - 1 bands.
@@ -201,6 +200,8 @@ int frame_create_impl(const pt_scene *scene, const int32_t *devices, int32_t n_b
         }
     }
     if (f->transport == PT_FRAME_TRANSPORT_RCCL) {
+        PT_HIP_TRY(hipSetDevice(root));
+        PT_HIP_TRY(hipStreamCreateWithFlags(&f->gather_stream, hipStreamNonBlocking));   // the receives of the gather
         Rccl &r = rccl();
         if (!r.error.empty()) return fail(PT_ERR_UNSUPPORTED, r.error);
         f->comms.assign(f->devices.size(), nullptr);
@@ -286,8 +287,10 @@ int frame_wait_impl(pt_frame *f) {
         PT_HIP_TRY(hipSetDevice(s->scene->device));
         PT_HIP_TRY(hipStreamSynchronize(s->stream));
     }
-    PT_HIP_TRY(hipSetDevice(f->devices[0]));
-    PT_HIP_TRY(hipStreamSynchronize(f->gather_stream));
+    if (f->gather_stream) {
+        PT_HIP_TRY(hipSetDevice(f->devices[0]));
+        PT_HIP_TRY(hipStreamSynchronize(f->gather_stream));
+    }
     return PT_OK;
 }
 
@@ -306,8 +309,10 @@ int frame_read_impl(pt_frame *f, float *sum, float *sum2, int32_t *count) {
 int frame_clear_impl(pt_frame *f) {
     if (!f) return fail(PT_ERR_INVALID_ARGUMENT, "null frame");
     // the receives of a gather still in flight write into the root planes: they finish first
-    PT_HIP_TRY(hipSetDevice(f->devices[0]));
-    PT_HIP_TRY(hipStreamSynchronize(f->gather_stream));
+    if (f->gather_stream) {
+        PT_HIP_TRY(hipSetDevice(f->devices[0]));
+        PT_HIP_TRY(hipStreamSynchronize(f->gather_stream));
+    }
     for (pt_session *s : f->sessions) {
         const int rc = pt_session_clear(s);
         if (rc != PT_OK) return rc;

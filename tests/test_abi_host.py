@@ -178,3 +178,24 @@ def test_clone_shares_the_host_side_and_frame_needs_a_device(models_dir):
         with pytest.raises(pt.PtError) as e:
             pt.Frame(c, [0], 64, 64)
         assert e.value.status == 4                    # PT_ERR_NO_DEVICE: no CPU fallback
+
+
+def test_threaded_resolve_is_the_sequential_resolve_bit_for_bit():
+    """Above 2^18 pixels pt_resolve runs bands of rows on several cores; what depends on the pixel order (the float sum of the
+    dispersion terms, ties and signed zeros of max / min) must come out as the reference's sequential loop computes it
+    (main.cpp:162-185, restated in the oracle)."""
+    rng = np.random.default_rng(5)
+    W, H = 1024, 600
+    n = W * H
+    c = rng.integers(0, 4, n).astype(np.int32)
+    s = (rng.random((n, 3)) * c[:, None]).astype(np.float32)
+    s2 = (s * s / np.maximum(c, 1)[:, None]).astype(np.float32)          # variance estimates around +-0: signed zeros and ties
+    s2[::7] *= np.float32(1.5)
+    got_bgr, got_d = pt.resolve(W, H, s, s2, c)
+    ref_bgr, ref_d = O.resolve(W, H, s, s2, c)
+    assert np.array_equal(got_bgr, ref_bgr)
+    assert np.array_equal(np.asarray(got_d, np.float32).view(np.uint32), np.asarray(ref_d, np.float32).view(np.uint32))
+    got_rgb, got_d2 = pt.resolve_float(W, H, s, s2, c)
+    ref_rgb, _ = O.resolve_float(W, H, s, s2, c)
+    assert np.array_equal(got_rgb.view(np.uint32), np.asarray(ref_rgb, np.float32).reshape(got_rgb.shape).view(np.uint32))
+    assert np.array_equal(np.asarray(got_d2, np.float32).view(np.uint32), np.asarray(got_d, np.float32).view(np.uint32))

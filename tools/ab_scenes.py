@@ -46,6 +46,7 @@ def main():
     if a.sweep:
         knob, values = a.sweep.split("=")
         runs = [("testhooks", float(v)) for v in values.split(",")]
+    baseline = {}   # scene -> frame digest of the block's first run: every variant must render the same frame
     for name, mode in runs:
         L = pt.load_library(os.path.join(ROOT, "path-tracing_amd", "lib", f"libpt_{name}.so"))
         if mode is not None:
@@ -73,6 +74,13 @@ def main():
                   f"node rounds/wseg {st['wave_node_rounds'] / ws:.2f}  exact rounds/wseg {st['wave_exact_iterations'] / ws:.2f}  "
                   f"exact/seg {st['exact_tests'] / max(1, st['segments']):.3f}  partial {st['partial_commit_rounds']}  frame {digest}", flush=True)
             sc.close()
+            if a.sweep or a.order_modes:
+                continue    # (table-builder knobs keep the frame as well, but each run is its own baseline there)
+            if baseline.setdefault(sn, digest) != digest:
+                # a variant that renders another frame is WRONG, not slow: stop the block here instead of timing more of it
+                # (round 2's ab20 went on after a digest change and ended in a memory fault, profiles/r02_ab_logs.txt)
+                print(f"DIGEST MISMATCH: {name} on {sn} renders {digest}, the block's baseline {baseline[sn]}: stopping", flush=True)
+                sys.exit(3)
 
 
 if __name__ == "__main__":
