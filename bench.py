@@ -110,6 +110,12 @@ def visible_devices():
                 n += 1
         except (OSError, ValueError):
             pass
+    if n == 0:      # topology not readable here: ask the runtime, but in a short-lived child, never in this process
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=180)
+            n = int(r.stdout.strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+            n = 0
     return n
 
 

@@ -198,7 +198,6 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.clusters = scene->cull.clusters;
     a.spheres = scene->cull.spheres;
     a.bary = scene->cull.bary;
-    a.n_bary = static_cast<uint32_t>(t.bary.size());
     a.bary_all = scene->cull.bary_all;
     a.a_max_all = ca.a_max; a.m0_all = ca.m0; a.t_guard_all = ca.t_guard;
     a.exact = scene->d_exact;

@@ -69,12 +69,6 @@ struct SmallQueues { static constexpr int kNodeStack = PT_SMALL_NODES, kPairQueu
 #define PT_BIG_WAVES (PT_WAVES_PER_SIMD - 2)   // waves per SIMD the big-scene and skybox instantiations are compiled for
 #endif
 struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };
-// The first records of the large class (the walls of a room) are also kept in LDS, one copy per wave: read from there they
-// are VGPR operands, and a fused multiply-add whose operands are all vector registers issues in about half the cycles of one
-// with a scalar-register operand (profiles/r02_issue_cost.txt: 2.6 against 4.1).  0 = scalar loads only.
-#ifndef PT_WALL_LDS
-#define PT_WALL_LDS 0
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -205,21 +199,6 @@ __device__ __forceinline__ CullRec load_cull(ConstF p) {
     return r;
 }
 typedef const __attribute__((address_space(4))) uint32_t *ConstU;
-#if PT_WALL_LDS > 0
-__device__ __forceinline__ CullRec load_cull_lds(const float4 *p) {   // the same address in every lane: an LDS broadcast
-    const float4 c0 = p[0], c1 = p[1], c2 = p[2];
-    CullRec r;
-    r.n[0] = c0.x; r.n[1] = c0.y; r.n[2] = c0.z; r.w = c0.w;
-    r.au[0] = c1.x; r.au[1] = c1.y; r.au[2] = c1.z; r.cu = c1.w;
-    r.av[0] = c2.x; r.av[1] = c2.y; r.av[2] = c2.z; r.cv = c2.w;
-    return r;
-}
-template <class Lds>
-__device__ __forceinline__ void stage_walls(const RenderArgs &a, Lds &lds, int lane) {
-    const uint32_t n4 = min(a.n_bary, static_cast<uint32_t>(PT_WALL_LDS)) * 3u;
-    for (uint32_t i = lane; i < n4; i += 64u) lds.wall[i] = reinterpret_cast<const float4 *>(a.bary)[i];
-}
-#endif
 
 // Keep the node iff the ray (not the whole line) comes within sqrt(r2) of the centre.  Written so that a NaN keeps.
 __device__ __forceinline__ bool sphere_keep(float cx, float cy, float cz, float r2, const Ray &q) {
@@ -376,9 +355,6 @@ struct WaveLds {
     uint32_t level_off[kMaxLevels];// sphere offset of each level of the cluster being walked
     uint32_t level_cnt[kMaxLevels];// number of real nodes of each level
     float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
-#if PT_WALL_LDS > 0
-    float4 wall[PT_WALL_LDS * 3];  // the first records of RenderArgs::bary (12 floats each)
-#endif
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0, w_partial = 0;   // wave-uniform, live in SGPRs
@@ -481,16 +457,8 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
         const float tnz = __builtin_fmaf(az, byte_to_float(up ? nz1 : nz0, k), nbz), tfz = __builtin_fmaf(az, byte_to_float(up ? fz1 : fz0, k), bz);
         const float t_in = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, t_min));
         const float t_out = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, t_best));
-#ifdef PT_BOX_ADDC
-        // experiment: the keep bit goes from the comparison's carry straight into the mask (children 0..7 end up in bits 7..0)
-        asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(t_in), "v"(t_out) : "vcc");
-#else
         m |= !(t_in > t_out) ? (1u << c) : 0u;   // a NaN keeps
-#endif
     }
-#ifdef PT_BOX_ADDC
-    m = __builtin_bitreverse32(m) >> 24;
-#endif
     return m;
 }
 
@@ -897,15 +865,6 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     m &= a.emis_large_w0;
                 } else
                 if (quads == pair_bits) {   // every record of the word is a quad (the walls of a room): no per-record dispatch
-#if PT_WALL_LDS > 0
-                    const uint32_t rec0 = off + kChunk * w;
-                    if (rec0 + cnt32 <= min(a.n_bary, static_cast<uint32_t>(PT_WALL_LDS))) {
-                        for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {
-                            const uint32_t rej = cull_reject_quad(load_cull_lds(lds.wall + 3 * (rec0 + k0)), q, k1, k2, a_max, m0q, t_guard);
-                            m |= (~rej & 3u) << k0;
-                        }
-                    } else
-#endif
                     for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {
                         const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
                         m |= (~rej & 3u) << k0;
@@ -1121,9 +1080,6 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
         }
         lds.acc[6][lane] = __int_as_float(a.count[p]);
     }
-#if PT_WALL_LDS > 0
-    stage_walls(a, lds, lane);
-#endif
     // Adaptive sampling (main.cpp:118-125) asks, before every pass > 10, whether the variance estimate of all three
     // channels is below `error`.  That is a pure function of the accumulators, which change only when this pixel's
     // path reaches an emitter, so the answer is cached in one bit and refreshed there: no per-pass re-reads.
@@ -1499,9 +1455,6 @@ __global__ __launch_bounds__(kBlock, BIG ? PT_BIG_WAVES : PT_WAVES_PER_SIMD) voi
     }
     // Rays outside the envelope the culling margins were derived for (pt_hip.h: pt_trace_rays_host) get every triangle as
     // a candidate for the exact test instead; written so that NaNs count as outside.
-#if PT_WALL_LDS > 0
-    stage_walls(a, lds, lane);
-#endif
     const float d2 = (q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz;
     const bool inside = __builtin_fabsf(q.ox) <= a.r_org && __builtin_fabsf(q.oy) <= a.r_org && __builtin_fabsf(q.oz) <= a.r_org &&
                         __builtin_fabsf(d2 - 1.0f) <= 1.0e-5f;

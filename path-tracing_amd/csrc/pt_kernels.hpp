@@ -14,7 +14,6 @@ struct RenderArgs {
     const ClusterDesc *clusters;   // cull hierarchy (pt_scene.hpp: CullTables), read through the scalar cache
     const SphereRec *spheres;
     const CullRec *bary;
-    uint32_t n_bary;               // records in `bary`
     const CullRec *bary_all;        // big scenes: one record per triangle for the pair pre-filter, else nullptr
     float a_max_all, m0_all, t_guard_all;
     const ExactRec *exact;    // n_tri records in the ORIGINAL triangle order: shading, the reference's all-triangles loop

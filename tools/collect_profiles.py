@@ -2,7 +2,7 @@
 """Copies what tools/profile_round.sh left under gpurun_out/<tag>/ into profiles/ (the tracked summaries) and prints the
 numbers the documents quote.
 
-    python tools/collect_profiles.py [--tag r02]
+    python tools/collect_profiles.py [--tag r03]
 
     profiles/<tag>_bench_1gpu.json        the default bench.py line
     profiles/<tag>_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command
@@ -72,7 +72,7 @@ def phase_shares(path, names):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--tag", default="r03")
     a = ap.parse_args()
     t = a.tag
     G = os.path.join(ROOT, "gpurun_out", t)
@@ -90,6 +90,14 @@ def main():
         if m:
             out[label] = m
     json.dump(out, open(os.path.join(P, f"{t}_pmc_detail.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(G, "hip_startup_probe.txt")):
+        head = ("# tools/hip_startup_probe.cpp, three fresh processes on the GPU box: seconds per HIP call of a program that does nothing else\n"
+                "# (runtime initialisation, first stream, first kernel, pinning, teardown = real - sum), then pt_render's own phases, cold.\n")
+        body = open(os.path.join(G, "hip_startup_probe.txt")).read()
+        if os.path.exists(os.path.join(G, "e2e_cold_phases.txt")):
+            body += "\n# pt_render --W 1920 --H 1080 -RPP 256 -TIMING 1 -FASTEXIT 1, three fresh processes (no other process on the GPU):\n" + \
+                    open(os.path.join(G, "e2e_cold_phases.txt")).read()
+        open(os.path.join(P, f"{t}_hip_startup_probe.txt"), "w").write(head + body)
     names = ["ray generation / loop control", "cluster + top-level tests", "tree walk (box-tree rounds)", "barycentric cull of the large class",
              "pair publication", "exact rounds (final drains)", "pre-filter + exact inside the box walk", "shading"]
     txt = ["# Per-phase shares of the waves' shader-clock cycles (diagnostic build libpt_phase.so, -DPT_PHASE_TIMERS: s_memtime stamps).",

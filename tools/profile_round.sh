@@ -9,14 +9,14 @@
 #   phase_*.log          per-phase shader-clock shares from the diagnostic build (libpt_phase.so)
 #   blockprof_*          execution counters of the instrumented code object (libpt_blockprof.so + lib/blockprof/pt_bp.hsaco)
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 10 --warmup 2 --save-pmc "$O/pmc_hbm.json" > "$O/bench_1gpu.json" 2> "$O/bench_1gpu.err"
 echo "bench done"
-rocprofv3 --kernel-trace --stats -d "$O/kt" -o kt --output-format csv -- python3 "$R/bench.py" --cpu-seconds 0 --pmc off --no-configs3 > "$O/kt.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$O/kt" -o kt --output-format csv -- python3 "$R/bench.py" --cpu-seconds 0 --pmc off --no-configs3 --no-extra-legs > "$O/kt.log" 2>&1
 echo "kernel trace done"
 python3 "$R/tools/run_configs.py" > "$O/configs.jsonl" 2> "$O/configs.err"
 echo "configs done"
@@ -43,4 +43,8 @@ echo "phase timers done"
 PT_BLOCKPROF_OUT=$O/blockprof_tor python3 "$R/tools/blockprof_run.py" tor 8 > "$O/blockprof_tor.log" 2>&1
 PT_BLOCKPROF_OUT=$O/blockprof_x64 python3 "$R/tools/blockprof_run.py" x64 4 > "$O/blockprof_x64.log" 2>&1
 echo "block profile done"
+# where a fresh process spends its time outside the kernels (runtime start-up, first calls, teardown)
+for i in 1 2 3; do ( time "$R/path-tracing_amd/lib/tools/hip_startup_probe" ) >> "$O/hip_startup_probe.txt" 2>&1; done
+for i in 1 2 3; do "$PTR" --W 1920 --H 1080 -RPP 256 -MRR 8 -ERR -1 -UPDATE 0 -QUIET 1 -MODEL_PATH "$R/models/" -OUT /tmp/e2e.bmp -TIMING 1 -FASTEXIT 1 -T0_NS $(date +%s%N) 2>> "$O/e2e_cold_phases.txt" > /dev/null; done
+echo "start-up probe done"
 tail -c 400 "$O/bench_1gpu.json"
