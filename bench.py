@@ -632,7 +632,8 @@ def main():
                          "hbm": {"algorithmic_bytes": algo_bytes, "traffic_bytes": traffic,
                                  "traffic_over_algorithmic": traffic / algo_bytes if traffic else None,
                                  "chunks_per_tile": n_chunks,
-                                 "why": "each tile's accumulators are re-read and re-written once per pass-range chunk of the launch",
+                                 "why": "the timed kernel (two pixels per lane) leaves the accumulators in memory: read once per pass-range chunk for the "
+                                        "adaptive-sampling state, read-modify-written (three sparse cache lines) when a path reaches an emitter",
                                  "achieved": (traffic or algo_bytes) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": ((traffic or algo_bytes) / (kms * 1e-3) / 1e9) / PEAK_HBM_GBS if kms > 0 else 0.0}},

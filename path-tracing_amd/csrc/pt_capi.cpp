@@ -251,15 +251,17 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
     a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
     a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
     a.error = p->error; a.seed = p->seed;
-    a.blocks_x = (p->width + pt::kTileW - 1) / pt::kTileW;
-    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
-    if (n_tiles == 0) return PT_OK;
+    if (p->row_end == p->row_begin) return PT_OK;
     int rc = ctx_ready(ctx);
     if (rc != PT_OK) return rc;
     if (want_stats) {
         if ((rc = ctx_stats_ready(ctx)) != PT_OK) return rc;
         a.stats = ctx.d_stats;
     }
+    // one wave = one tile of 8 rows; how many pixels wide depends on the instantiation this launch runs
+    const int tile_w = pt::integrator_tile_width(a);
+    a.blocks_x = (p->width + tile_w - 1) / tile_w;
+    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
     // Scheduler: cut the pass range into chunks so that the tail of the launch is balanced with small work items.  A tile's
     // chunks run in order and each re-reads and re-writes the tile's accumulators, so there should be few of them: chunk c
     // takes 3/4 of the passes that are left (256 passes: 192 + 48 + 16), the last one at least 4 and less than 32.

@@ -53,6 +53,14 @@ constexpr int kBlock = 64;                // one wave = one 8x8 pixel tile per w
 #define PT_SMALL_PAIRS 256
 #endif
 struct SmallQueues { static constexpr int kNodeStack = PT_SMALL_NODES, kPairQueue = PT_SMALL_PAIRS, kFiltered = 1; };
+// the same for the small-scene kernel with two rays per lane (twice the items per wave-segment)
+#ifndef PT_SMALL2_NODES
+#define PT_SMALL2_NODES 160
+#endif
+#ifndef PT_SMALL2_PAIRS
+#define PT_SMALL2_PAIRS 256
+#endif
+struct SmallQueues2 { static constexpr int kNodeStack = PT_SMALL2_NODES, kPairQueue = PT_SMALL2_PAIRS, kFiltered = 1; };
 #ifndef PT_BIG_NODES
 #define PT_BIG_NODES 384      // measured on the 16 398- and 49 934-triangle scenes: 832 / 512 (4 waves per SIMD) is 4 % slower,
 #endif
@@ -338,23 +346,37 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // Closest hit of every lane's ray: Scene::TraceRay's loop (scene.cpp:114-120) for one wave.  Wave-uniform control
 // flow: all 64 lanes must call it together; lanes with valid == false take part in the shared work only.
 // ---------------------------------------------------------------------------------------------------------------
-template <class Q>
+// R = rays per lane.  A wave owns 64 R pixels (an 8R x 8 tile) and a wave-segment searches 64 R rays: lane l carries rays
+// l, l + 64, ...  Everything wave-uniform about a segment (the scalar half of the large-class loop, the cluster loop, queue
+// bookkeeping) is then shared by R times the rays, and the lane-balanced rounds (sphere-tree items, exact pairs) are that much
+// fuller -- for Tor.obj, where 9 % of the rays come near the torus and a segment yields 1.5 pairs per ray, that is where a sixth
+// of the instructions went.  Big scenes keep R = 1 (their rounds are full anyway, their registers are not).
+template <int N> struct AccPlanes { float v[7][N]; };
+template <> struct AccPlanes<0> {};
+template <class Q, int R>
 struct WaveLds {
+    static constexpr int kRays = R, kSlots = 64 * R;
     static constexpr int kNodeStack = Q::kNodeStack, kPairQueue = Q::kPairQueue;
     static constexpr bool kPrefilter = Q::kFiltered > 1;   // big scenes: thin the pairs with the barycentric test first
+    static_assert(R == 1 || R == 2, "ray ids take 6 or 7 bits of a work item");
+    static_assert(R == 1 || !kPrefilter, "the box-tree walk and its pre-filter are written for one ray per lane");
+    // work-item layouts: sphere-tree stack entries = ray << kNodeSrcShift | level << kNodeLevShift | node index within its level;
+    // pairs = slot | ray << 24 (| kUnfiltered << 24 with the pre-filter)
+    static constexpr uint32_t kSrcMask = kSlots - 1, kNodeSrcShift = R == 1 ? 26 : 25, kNodeLevShift = kNodeSrcShift - 3;
     // The code that fills the queues relies on these minima (see push_pairs_any, drain_pairs and the tree walk):
     static_assert(Q::kPairQueue >= 128, "push_pairs_any publishes slices of up to 128 pairs");
     static_assert(!kPrefilter || Q::kFiltered >= 128, "the pre-filter appends up to 64 survivors to up to 63 waiting ones");
     static_assert(!kPrefilter || Q::kFiltered >= PT_BIG_EXACT_AT - 1 + 64, "up to PT_BIG_EXACT_AT - 1 pairs wait when 64 survivors are appended");
     static_assert(Q::kNodeStack >= 64, "a round pops up to 64 nodes");
     uint32_t filtered[Q::kFiltered];   // pairs that survived the pre-filter, waiting for a full exact round
-    unsigned long long best[64];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
-    float ray[6][64];              // this segment's rays, readable by every lane
-    uint32_t nodes[kNodeStack + 64];// LIFO of tree nodes to expand: lane << 26 | level << 23 | node index within its level
-    uint32_t pairs[kPairQueue];    // (ray, triangle) work items: slot index | lane << 24 | kUnfiltered << 24
+    unsigned long long best[kSlots];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
+    float ray[6][kSlots];          // this segment's rays, readable by every lane
+    uint32_t nodes[kNodeStack + 64];// LIFO of tree nodes to expand (layout above; the box tree: ray << 26 | node)
+    uint32_t pairs[kPairQueue];    // (ray, triangle) work items
     uint32_t level_off[kMaxLevels];// sphere offset of each level of the cluster being walked
     uint32_t level_cnt[kMaxLevels];// number of real nodes of each level
-    float acc[7][64];              // this tile's accumulators: sum rgb, sum2 rgb, count (int bits)
+    AccPlanes<R == 1 ? kSlots : 0> acc;   // R = 1: this tile's accumulators (sum rgb, sum2 rgb, count as int bits); R > 1: they stay in memory
+    static constexpr bool kAccInLds = R == 1;
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0, w_partial = 0;   // wave-uniform, live in SGPRs
@@ -482,12 +504,22 @@ __device__ __forceinline__ unsigned long long brute_force_key(const RenderArgs &
 // the closest hit among a SUPERSET of the emitters, which is all the caller needs to know whether the ray's closest hit can be
 // one (see the last segment in the kernel).
 template <bool ENV, bool EMIS, class Lds, class Stats>
-__device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray &q, bool live, bool in_envelope, int lane,
-                                            float eps, float &best, int &hit, const ExactRec *&hit_rec, Stats &st, bool emis_flag = false) {
+__device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray (&q)[Lds::kRays], const bool (&live)[Lds::kRays],
+                                            const bool (&in_envelope)[Lds::kRays], int lane, float eps, float (&best)[Lds::kRays],
+                                            int (&hit)[Lds::kRays], const ExactRec *(&hit_rec)[Lds::kRays], Stats &st, bool emis_flag = false) {
+    constexpr int R = Lds::kRays;   // rays per lane: ray k of lane l has the id l + 64 k
     const bool emis_only = EMIS && emis_flag;
     // `valid` below = rays that go through the culling hierarchy; live rays outside the envelope its margins were derived
     // for get every slot as a candidate instead (rare: see the caller).
-    const bool valid = live && in_envelope;
+    bool valid[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) valid[k] = live[k] && in_envelope[k];
+    auto any_ray = [&](const bool (&b)[R]) {   // wave-uniform: does any ray of the wave-segment have the flag?
+        bool x = b[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k) x = x || b[k];
+        return __any(x);
+    };
     constexpr uint32_t kNodeStack = Lds::kNodeStack, kPairQueue = Lds::kPairQueue;
     // Small scenes (at most kBigSceneTriangles = 2048 triangles, so 16 bits each): the closest-hit key carries the SLOT
     // below the original index, and shading reads the slot-ordered record the exact test has just pulled through the
@@ -496,9 +528,13 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     static_assert(kBigSceneTriangles < 65536, "packed (original index, slot) key");
     ++st.w_segments;
     PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
-    lds.best[lane] = ~0ull;
-    lds.ray[0][lane] = q.ox; lds.ray[1][lane] = q.oy; lds.ray[2][lane] = q.oz;
-    lds.ray[3][lane] = q.dx; lds.ray[4][lane] = q.dy; lds.ray[5][lane] = q.dz;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int id = lane + 64 * k;
+        lds.best[id] = ~0ull;
+        lds.ray[0][id] = q[k].ox; lds.ray[1][id] = q[k].oy; lds.ray[2][id] = q[k].oz;
+        lds.ray[3][id] = q[k].dx; lds.ray[4][id] = q[k].dy; lds.ray[5][id] = q[k].dz;
+    }
     uint32_t n_pairs = 0;   // wave-uniform fill level of lds.pairs
     wave_sync();
 
@@ -511,7 +547,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         ++st.w_exact_iters;
         st.n_exact += cnt;
         if (active) {
-            const uint32_t src = (e >> 24) & 63u, tri = e & 0xFFFFFFu;
+            const uint32_t src = (e >> 24) & Lds::kSrcMask, tri = e & 0xFFFFFFu;
             Ray r;
             r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
             r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
@@ -565,50 +601,74 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             wave_sync();
         }
     };
-    // Append one pair per set bit of `bits` (bit j = triangle tri0 + j of ray `src`): a prefix sum over the lanes' counts
-    // gives every lane its place in the queue (and the total).  `excl` / `total` come from wave_scan_inclusive of the
-    // lanes' popcounts; the caller guarantees room for `total` pairs.
+    // Append one pair per set bit of `bits[k]` (bit j = triangle tri0 + j of this lane's ray k): a prefix sum over the lanes'
+    // counts gives every lane its place in the queue (and the total).  `flag` is or-ed into the ray id (kUnfiltered).
+    auto emit_lane_pairs = [&](const uint32_t (&bits)[R], uint32_t tri0, uint32_t flag, uint32_t excl, uint32_t total) {
+        uint32_t pos = n_pairs + excl;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            emit_bits(lds.pairs, pos, bits[k], tri0 | ((static_cast<uint32_t>(lane + 64 * k) | flag) << 24));
+            pos += __builtin_popcount(bits[k]);
+        }
+        n_pairs += total;
+        wave_sync();
+    };
+    // the same for entries of other lanes' rays (root round): one mask per lane, ray id `src`
     auto emit_pairs = [&](uint32_t bits, uint32_t tri0, uint32_t src, uint32_t excl, uint32_t total) {
         emit_bits(lds.pairs, n_pairs + excl, bits, tri0 | (src << 24));
         n_pairs += total;
         wave_sync();
     };
-    // for masks of any width: makes room first, and slices the mask if one batch could exceed the queue
-    auto push_pairs_any = [&](uint32_t bits, uint32_t tri0, uint32_t src) {
-        const uint32_t cnt = __builtin_popcount(bits);
+    // for masks of any width: makes room first, and slices the masks if one batch could exceed the queue
+    auto push_pairs_any = [&](const uint32_t (&bits)[R], uint32_t tri0, uint32_t flag) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) cnt += __builtin_popcount(bits[k]);
         const uint32_t incl = wave_scan_inclusive(cnt), total = wave_last(incl);
         if (total == 0) return;
         if (n_pairs + total > kPairQueue) drain_pairs(0);
         if (total <= kPairQueue) {
-            emit_pairs(bits, tri0, src, incl - cnt, total);
+            emit_lane_pairs(bits, tri0, flag, incl - cnt, total);
             return;
         }
-        for (uint32_t lo = 0; lo < 32u; lo += 2u) {   // <= 128 pairs per slice
-            const uint32_t part = bits & (3u << lo);
-            if (!__any(part != 0)) continue;
+        constexpr uint32_t kSlice = 2u / R;   // bits of every ray's mask per slice: <= 128 pairs
+        for (uint32_t lo = 0; lo < 32u; lo += kSlice) {
+            uint32_t part[R], pc2 = 0;
+            bool some = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                part[k] = bits[k] & (((1u << kSlice) - 1u) << lo);
+                pc2 += __builtin_popcount(part[k]);
+                some = some || part[k] != 0;
+            }
+            if (!__any(some)) continue;
             if (n_pairs + 128u > kPairQueue) drain_pairs(0);
-            const uint32_t pc2 = __builtin_popcount(part);
             const uint32_t in2 = wave_scan_inclusive(pc2);
-            emit_pairs(part, tri0, src, in2 - pc2, wave_last(in2));
+            emit_lane_pairs(part, tri0, flag, in2 - pc2, wave_last(in2));
         }
     };
 
     // Candidate masks of runs that need no tree walk (large-triangle words, runs of at most 8 small triangles) are
     // collected in a window of 32 consecutive triangle indices and published together: adjacent short runs (the walls
     // and the light of a room, split by the file order into three clusters) then cost one publication, not three.
-    uint32_t pend = 0, pend_tri0 = 0;   // per-lane bits; wave-uniform window start
+    uint32_t pend[R], pend_tri0 = 0;    // per-ray bits; wave-uniform window start
+#pragma unroll
+    for (int k = 0; k < R; ++k) pend[k] = 0;
     bool pend_open = false;             // wave-uniform
     auto flush_pending = [&]() {
-        if (pend_open) push_pairs_any(pend, pend_tri0, static_cast<uint32_t>(lane));
-        pend = 0;
+        if (pend_open) push_pairs_any(pend, pend_tri0, 0u);
+#pragma unroll
+        for (int k = 0; k < R; ++k) pend[k] = 0;
         pend_open = false;
     };
-    auto add_pending = [&](uint32_t bits, uint32_t tri0, uint32_t width) {   // tri0, width wave-uniform
+    auto add_pending = [&](const uint32_t (&bits)[R], uint32_t tri0, uint32_t width) {   // tri0, width wave-uniform
         if (pend_open && tri0 >= pend_tri0 && tri0 + width <= pend_tri0 + 32u) {
-            pend |= bits << (tri0 - pend_tri0);
+#pragma unroll
+            for (int k = 0; k < R; ++k) pend[k] |= bits[k] << (tri0 - pend_tri0);
         } else {
             flush_pending();
-            pend = bits;
+#pragma unroll
+            for (int k = 0; k < R; ++k) pend[k] = bits[k];
             pend_tri0 = tri0;
             pend_open = true;
         }
@@ -616,12 +676,19 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 
     // ---- 0. rays outside the envelope: all slots are candidates (padding slots carry NaN planes and are never accepted);
     // their pairs carry bit 30 = "skip the barycentric pre-filter", whose margins assume the envelope as well
-    if constexpr (ENV) if (__builtin_expect(__any(live && !in_envelope), 0)) {
-        const bool far = live && !in_envelope;
-        for (uint32_t base = 0; base < a.n_slots; base += 32u) {
-            const uint32_t left = a.n_slots - base;
-            const uint32_t all = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
-            push_pairs_any(far ? all : 0u, base, static_cast<uint32_t>(lane) | kUnfiltered);
+    if constexpr (ENV) {
+        bool far[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) far[k] = live[k] && !in_envelope[k];
+        if (__builtin_expect(any_ray(far), 0)) {
+            for (uint32_t base = 0; base < a.n_slots; base += 32u) {
+                const uint32_t left = a.n_slots - base;
+                const uint32_t all = left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                uint32_t bits[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) bits[k] = far[k] ? all : 0u;
+                push_pairs_any(bits, base, Lds::kPrefilter ? kUnfiltered : 0u);
+            }
         }
     }
 
@@ -639,8 +706,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         // instantiations leave that code out, which spares them its registers)
         constexpr bool kSphereTrees = !Lds::kPrefilter;
         if (!kSphereTrees && kind == 0) continue;
-        const bool pc = (kSphereTrees && kind == 0) ? valid & sphere_keep(cp[0], cp[1], cp[2], cp[3], q) : valid;
-        if (!__any(pc)) continue;
+        bool pc[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) pc[k] = (kSphereTrees && kind == 0) ? valid[k] & sphere_keep(cp[0], cp[1], cp[2], cp[3], q[k]) : valid[k];
+        if (!any_ray(pc)) continue;
         if (kSphereTrees && kind == 0) {
             // ---- small triangles: an 8-ary tree of bounding spheres, walked with a wave-wide LIFO of (ray, node) items
             const uint32_t n_levels = ((ConstU)cp)[8];
@@ -651,21 +720,58 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             }
             wave_sync();
             uint32_t n_nodes = 0;   // wave-uniform fill level of lds.nodes
-            uint32_t tmask = 0;
+            uint32_t tmask[R];      // per ray: top-level nodes still to be pushed
+#pragma unroll
+            for (int k = 0; k < R; ++k) tmask[k] = 0;
+            auto any_tmask = [&]() {
+                uint32_t x = tmask[0];
+#pragma unroll
+                for (int k = 1; k < R; ++k) x |= tmask[k];
+                return __any(x != 0);
+            };
+            // pushes one top-level node per ray and step until nothing is left or the stack is full (the rest follows once it has drained)
+            auto push_top = [&](uint32_t top) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    while (__any(tmask[k] != 0)) {   // at most 8 x 64 R items > capacity: drained in the expansion loop before overflow
+                        const bool has = tmask[k] != 0;
+                        const unsigned long long ball = __ballot(has);
+                        if (n_nodes + __builtin_popcountll(ball) > kNodeStack) return;
+                        if (has) {
+                            const uint32_t j = __builtin_ctz(tmask[k]);
+                            tmask[k] &= tmask[k] - 1;
+                            lds.nodes[n_nodes + lanes_below(ball)] = (static_cast<uint32_t>(lane + 64 * k) << Lds::kNodeSrcShift) | (top << Lds::kNodeLevShift) | j;
+                        }
+                        n_nodes += __builtin_popcountll(ball);
+                    }
+                }
+            };
             // (a') Few rays near a small tree: skip its top level.  The (at most 16) lanes that passed the cluster sphere are
             // compacted, each gets 4 to 64 lanes, and together they test ALL nodes of the level below the top (at most 8
             // per lane) in one round -- instead of the wave-uniform top-level tests plus a round that is mostly empty.
             bool rooted = false;
             if (top >= 1) {
-                const unsigned long long pcb = __ballot(pc);
-                const uint32_t rcnt = __builtin_popcountll(pcb);
+                unsigned long long pcb[R];
+                uint32_t rcnt = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    pcb[k] = __ballot(pc[k]);
+                    rcnt += __builtin_popcountll(pcb[k]);
+                }
                 const uint32_t clev = top - 1;
                 const uint32_t nchild = (n_tri + (1u << (3 * clev)) - 1u) >> (3 * clev);
                 const uint32_t sh = rcnt <= 1u ? 6u : rcnt <= 2u ? 5u : rcnt <= 4u ? 4u : rcnt <= 8u ? 3u : rcnt <= 16u ? 2u : 0u;   // lanes per ray
                 const uint32_t per = (nchild + (1u << sh) - 1u) >> sh;                                                           // nodes per lane
                 if (rcnt <= 16u && per <= 8u) {
                     ++st.w_node_rounds;
-                    if (pc) lds.nodes[lanes_below(pcb)] = static_cast<uint32_t>(lane);   // the stack is empty here
+                    {
+                        uint32_t at = 0;   // the stack is empty here: the compacted ray ids go to its bottom
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            if (pc[k]) lds.nodes[at + lanes_below(pcb[k])] = static_cast<uint32_t>(lane + 64 * k);
+                            at += __builtin_popcountll(pcb[k]);
+                        }
+                    }
                     wave_sync();
                     // Lane `sub` of a ray's group takes nodes sub, sub + group, sub + 2 group, ...: one load instruction then
                     // reads consecutive records across the group (whole cache lines) instead of one line per lane.  When
@@ -707,7 +813,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                         }
                     } else if (tot <= kNodeStack) {
                         // bit j = node c0 + j * cstep of level clev (cstep = 1 << sh here)
-                        emit_bits(lds.nodes, n_nodes + incl - mc, m, (src << 26) | (clev << 23) | c0, sh);
+                        emit_bits(lds.nodes, n_nodes + incl - mc, m, (src << Lds::kNodeSrcShift) | (clev << Lds::kNodeLevShift) | c0, sh);
                         n_nodes += tot;
                         wave_sync();
                         rooted = true;
@@ -720,44 +826,29 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             const uint32_t top_off = top == 0 ? 0u : ((ConstU)cp)[8 + top];
             const uint32_t top_cnt = (n_tri + (1u << (3 * top)) - 1u) >> (3 * top);
             const ConstF tp = spheres + 4 * (static_cast<size_t>(off) + top_off);
-            for (uint32_t j = 0; j < top_cnt; ++j)
-                tmask |= sphere_keep(tp[4 * j], tp[4 * j + 1], tp[4 * j + 2], tp[4 * j + 3], q) ? (1u << j) : 0u;
-            tmask = pc ? tmask : 0u;
+            for (uint32_t j = 0; j < top_cnt; ++j) {
+                const float sx = tp[4 * j], sy = tp[4 * j + 1], sz = tp[4 * j + 2], sr = tp[4 * j + 3];
+#pragma unroll
+                for (int k = 0; k < R; ++k) tmask[k] |= sphere_keep(sx, sy, sz, sr, q[k]) ? (1u << j) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) tmask[k] = pc[k] ? tmask[k] : 0u;
             PT_STAMP(st, 1);   // cluster + top-level sphere tests
             if (top == 0) {
                 add_pending(tmask, first_tri, n_tri);   // the run has at most 8 triangles
-                tmask = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) tmask[k] = 0;
             } else {
-                while (__any(tmask != 0)) {   // at most 8 x 64 = 512 items > capacity: drained in the loop below before overflow
-                    const bool has = tmask != 0;
-                    const unsigned long long ball = __ballot(has);
-                    if (n_nodes + __builtin_popcountll(ball) > kNodeStack) break;   // rest is pushed after the stack has drained
-                    if (has) {
-                        const uint32_t j = __builtin_ctz(tmask);
-                        tmask &= tmask - 1;
-                        lds.nodes[n_nodes + lanes_below(ball)] = (static_cast<uint32_t>(lane) << 26) | (top << 23) | j;
-                    }
-                    n_nodes += __builtin_popcountll(ball);
-                }
+                push_top(top);
                 wave_sync();
             }
             }
             // (b) lane-balanced expansion: lane l takes the l-th item from the top of the stack, tests the node's 8
             // children against that item's ray and pushes the survivors (tree nodes back on the stack, triangles as
             // (ray, triangle) pairs).  A round is committed only for the top k lanes whose children fit.
-            while (n_nodes > 0 || __any(tmask != 0)) {
+            while (n_nodes > 0 || any_tmask()) {
                 if (n_nodes == 0) {   // top-level items that did not fit earlier
-                    while (__any(tmask != 0)) {
-                        const bool has = tmask != 0;
-                        const unsigned long long ball = __ballot(has);
-                        if (n_nodes + __builtin_popcountll(ball) > kNodeStack) break;
-                        if (has) {
-                            const uint32_t j = __builtin_ctz(tmask);
-                            tmask &= tmask - 1;
-                            lds.nodes[n_nodes + lanes_below(ball)] = (static_cast<uint32_t>(lane) << 26) | (top << 23) | j;
-                        }
-                        n_nodes += __builtin_popcountll(ball);
-                    }
+                    push_top(top);
                     wave_sync();
                 }
                 ++st.w_node_rounds;
@@ -771,9 +862,9 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     const uint32_t item = static_cast<uint32_t>(lane) >> shift, sub = static_cast<uint32_t>(lane) & ((1u << shift) - 1u);
                     if (item < cnt) {
                         const uint32_t e = lds.nodes[n_nodes - 1 - item];
-                        src = e >> 26;
-                        level = (e >> 23) & 7u;
-                        child0 = (e & 0x7FFFFFu) * kFan;   // index of the first child within level-1
+                        src = e >> Lds::kNodeSrcShift;
+                        level = (e >> Lds::kNodeLevShift) & 7u;
+                        child0 = (e & ((1u << Lds::kNodeLevShift) - 1u)) * kFan;   // index of the first child within level-1
                         Ray r;
                         r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                         r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
@@ -828,7 +919,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 {
                     const uint32_t excl = incl - packed;
                     emit_bits(leaf ? lds.pairs : lds.nodes, leaf ? n_pairs + (excl >> 16) : n_nodes + (excl & 0xFFFFu), m8,
-                              leaf ? ((first_tri + child0) | (src << 24)) : ((src << 26) | ((level - 1) << 23) | child0));
+                              leaf ? ((first_tri + child0) | (src << 24)) : ((src << Lds::kNodeSrcShift) | ((level - 1) << Lds::kNodeLevShift) | child0));
                     n_nodes += tot & 0xFFFFu;
                     n_pairs += tot >> 16;
                 }
@@ -846,44 +937,51 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 const uint32_t left = n_tri - kChunk * w;
                 const ConstF bp = bary + 12 * (static_cast<size_t>(off) + kChunk * w);
                 const uint32_t quads = w < kMaxLevels - 1 ? ((ConstU)cp)[9 + w] : 0u;   // bit k: slots k, k+1 are one quad record
-                uint32_t m = 0;
+                uint32_t m[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) m[k] = 0;
                 const uint32_t cnt32 = min(left, 32u);
                 const uint32_t pair_bits = 0x55555555u & (cnt32 >= 32u ? 0xFFFFFFFFu : ((1u << cnt32) - 1u));
+                // one record (wave-uniform, in scalar registers) against this lane's R rays
+                auto quad = [&](uint32_t k0) {
+                    const CullRec rec = load_cull(bp + 12 * k0);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) m[k] |= (~cull_reject_quad(rec, q[k], k1, k2, a_max, m0q, t_guard) & 3u) << k0;
+                };
+                auto single = [&](uint32_t slot) {
+                    const CullRec rec = load_cull(bp + 12 * slot);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) m[k] |= cull_reject(rec, q[k], k1, k2, a_max, m0, t_guard) ? 0u : (1u << slot);
+                };
                 if (emis_only && n_words == 1) {   // only the records that hold an emitter (the light of a room: one quad)
                     for (uint32_t rest = (a.emis_large_w0 | (a.emis_large_w0 >> 1)) & pair_bits; rest != 0; rest &= rest - 1) {
                         const uint32_t k0 = __builtin_ctz(rest);
                         if ((quads >> k0) & 1u) {
-                            const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
-                            m |= (~rej & 3u) << k0;
+                            quad(k0);
                         } else {
-                            for (uint32_t j = 0; j < 2; ++j) {
-                                const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
-                                m |= rej ? 0u : (1u << (k0 + j));
-                            }
+                            single(k0);
+                            single(k0 + 1);
                         }
                     }
-                    m &= a.emis_large_w0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) m[k] &= a.emis_large_w0;
                 } else
                 if (quads == pair_bits) {   // every record of the word is a quad (the walls of a room): no per-record dispatch
-                    for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {
-                        const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
-                        m |= (~rej & 3u) << k0;
-                    }
+                    for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) quad(k0);
                 } else
                 for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {   // records are padded to whole words
                     if ((quads >> k0) & 1u) {   // wave-uniform
-                        const uint32_t rej = cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard);
-                        m |= (~rej & 3u) << k0;
+                        quad(k0);
                     } else {
-#pragma unroll
-                        for (uint32_t j = 0; j < 2; ++j) {
-                            const bool rej = cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard);
-                            m |= rej ? 0u : (1u << (k0 + j));
-                        }
+                        single(k0);
+                        single(k0 + 1);
                     }
                 }
-                m = pc ? m : 0u;
-                m &= left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    m[k] = pc[k] ? m[k] : 0u;
+                    m[k] &= left >= 32u ? 0xFFFFFFFFu : ((1u << left) - 1u);
+                }
                 PT_STAMP(st, 3);   // barycentric cull of the large triangles
                 add_pending(m, first_tri + kChunk * w, min(left, 32u));
                 PT_STAMP(st, 4);   // pair publication
@@ -907,8 +1005,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             }
             uint32_t n_nodes;
             {
-                const unsigned long long vb = __ballot(valid);
-                if (valid) lds.nodes[lanes_below(vb)] = static_cast<uint32_t>(lane) << 26;   // the root, for every live ray
+                const unsigned long long vb = __ballot(valid[0]);
+                if (valid[0]) lds.nodes[lanes_below(vb)] = static_cast<uint32_t>(lane) << 26;   // the root, for every live ray
                 n_nodes = __builtin_popcountll(vb);
                 wave_sync();
             }
@@ -993,28 +1091,31 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         }
     }
     PT_STAMP(st, 5);   // exact rounds
-    const unsigned long long key = lds.best[lane];
-    const uint32_t key_lo = static_cast<uint32_t>(key);
-    hit = (key == ~0ull) ? -1 : static_cast<int>(kPackSlot ? key_lo >> 16 : key_lo);
-    hit_rec = kPackSlot ? a.exact_slot + (key_lo & 0xFFFFu) : a.exact + key_lo;   // dereferenced only if hit >= 0
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const unsigned long long key = lds.best[lane + 64 * k];
+        const uint32_t key_lo = static_cast<uint32_t>(key);
+        hit[k] = (key == ~0ull) ? -1 : static_cast<int>(kPackSlot ? key_lo >> 16 : key_lo);
+        hit_rec[k] = kPackSlot ? a.exact_slot + (key_lo & 0xFFFFu) : a.exact + key_lo;   // dereferenced only if hit >= 0
 #ifdef PT_VERIFY_BRUTE
-    // Verification build (libpt_verify.so, never the shipped library): Scene::TraceRay's loop as written -- every
-    // triangle through Triangle::Intersect for this lane's own ray -- and a comparison of the two closest hits.
-    {
-        const unsigned long long brute = brute_force_key(a, q, eps);
-        st.v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(live)));
-        const unsigned long long mine = (key == ~0ull) ? ~0ull : ((key & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(hit));
-        st.v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(live && brute != mine)));
-        if (live && brute != mine && a.stats) {   // one example for the host to print (any of them)
-            a.stats[11] = brute;
-            a.stats[12] = mine;
-            a.stats[13] = (static_cast<unsigned long long>(__float_as_uint(q.ox)) << 32) | __float_as_uint(q.oy);
-            a.stats[14] = (static_cast<unsigned long long>(__float_as_uint(q.oz)) << 32) | __float_as_uint(q.dx);
-            a.stats[15] = (static_cast<unsigned long long>(__float_as_uint(q.dy)) << 32) | __float_as_uint(q.dz);
+        // Verification build (libpt_verify.so, never the shipped library): Scene::TraceRay's loop as written -- every
+        // triangle through Triangle::Intersect for this lane's own ray -- and a comparison of the two closest hits.
+        {
+            const unsigned long long brute = brute_force_key(a, q[k], eps);
+            st.v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(live[k])));
+            const unsigned long long mine = (key == ~0ull) ? ~0ull : ((key & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(hit[k]));
+            st.v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(live[k] && brute != mine)));
+            if (live[k] && brute != mine && a.stats) {   // one example for the host to print (any of them)
+                a.stats[11] = brute;
+                a.stats[12] = mine;
+                a.stats[13] = (static_cast<unsigned long long>(__float_as_uint(q[k].ox)) << 32) | __float_as_uint(q[k].oy);
+                a.stats[14] = (static_cast<unsigned long long>(__float_as_uint(q[k].oz)) << 32) | __float_as_uint(q[k].dx);
+                a.stats[15] = (static_cast<unsigned long long>(__float_as_uint(q[k].dy)) << 32) | __float_as_uint(q[k].dz);
+            }
         }
-    }
 #endif
-    best = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
+        best[k] = (key == ~0ull) ? __builtin_inff() : from_ordered_bits(static_cast<uint32_t>(key >> 32));
+    }
     wave_sync();
 }
 
@@ -1028,9 +1129,18 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 // ENV = some triangle of the scene can be "hit" outside the envelope the culling margins are derived for (near-degenerate
 // triangles; CullTables::may_leave_envelope): every segment's origin is then checked.  A compile-time choice because the
 // mere presence of the rare path costs the common scenes 2 % (measured), whether or not it ever runs.
+#ifndef PT_RAYS_PER_LANE
+#define PT_RAYS_PER_LANE 2   // pixels (rays) per lane of the small-scene, statistics-free, skybox-free kernel; 1 = one 8 x 8 tile per wave
+#endif
+// rays per lane of an instantiation: the launch geometry (tile width) follows from it on the host as well
+template <bool SKY, bool BIG, bool STATS>
+constexpr int rays_per_lane() { return (!SKY && !BIG && !STATS) ? PT_RAYS_PER_LANE : 1; }
+
 template <bool SKY, bool BIG, bool STATS, bool ENV>
-__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
-    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;   // one wave per workgroup: all wave-private
+__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || rays_per_lane<SKY, BIG, STATS>() > 1) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+    constexpr int R = rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
+    constexpr int kTW = kTileW * R;
+    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
     // Work item = (pixel tile, chunk of passes), claimed from a ticket counter in chunk-major order: all tiles' first
@@ -1062,23 +1172,43 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
-    const int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTileW, tile_y0 = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;   // wave-uniform
-    const int x = tile_x0 + (lane % kTileW);
+    // a.blocks_x counts tiles of THIS instantiation's width (the host asks integrator_tile_width)
+    const int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTW, tile_y0 = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;   // wave-uniform
+    // pixel k of the lane: column (lane % 8) + 8 k of the tile, row lane / 8; its slot in the wave's LDS arrays is lane + 64 k
+    int x[R];
     const int y = tile_y0 + (lane / kTileW);
-    const bool in_image = x < a.width && y < a.row_end;
-    const size_t p = in_image ? (static_cast<size_t>(y - a.row_begin) * a.width + x) : 0;
-    const uint32_t gpix = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x);
+    bool in_image[R];
+    uint32_t gpix[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        x[k] = tile_x0 + (lane % kTileW) + kTileW * k;
+        in_image[k] = x[k] < a.width && y < a.row_end;
+        gpix[k] = static_cast<uint32_t>(static_cast<size_t>(y) * a.width + x[k]);
+    }
 
     // The tile's accumulators live in LDS for the whole launch (read once, written once: exactly the algorithmic
     // 56 B/pixel of HBM traffic).  Keeping them in VGPRs costs a wave per SIMD; read-modify-writing them in HBM at every
     // emitter hit moved 10x the algorithmic bytes, because each hit touches three sparse cache lines.
-    if (in_image) {
+    // Where the tile's accumulators live.  One ray per lane: in LDS for the whole work item (read once, written once: exactly
+    // the algorithmic 56 B/pixel of HBM traffic; keeping them in VGPRs costs a wave per SIMD).  Two rays per lane: in memory,
+    // read-modify-written when a path reaches an emitter (1 % of the samples): the 3.5 KB of LDS they would take are what
+    // separates 4 from 5 waves per SIMD there, worth 8 % of the frame time (profiles/r03_ab_logs.txt, ab52), while the extra
+    // traffic -- three sparse cache lines in and out per contribution, ~2 GB per 256-spp frame -- is 0.3 % of the HBM peak.
+    constexpr bool kAccInLds = decltype(lds)::kAccInLds;
+    if constexpr (kAccInLds) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lds.acc[k][lane] = a.sum[3 * p + k];
-            lds.acc[3 + k][lane] = a.sum2[3 * p + k];
+    for (int k = 0; k < R; ++k) {
+        if (in_image[k]) {
+            const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + x[k];
+            const int id = lane + 64 * k;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                lds.acc.v[c][id] = a.sum[3 * p + c];
+                lds.acc.v[3 + c][id] = a.sum2[3 * p + c];
+            }
+            lds.acc.v[6][id] = __int_as_float(a.count[p]);
         }
-        lds.acc[6][lane] = __int_as_float(a.count[p]);
+    }
     }
     // Adaptive sampling (main.cpp:118-125) asks, before every pass > 10, whether the variance estimate of all three
     // channels is below `error`.  That is a pure function of the accumulators, which change only when this pixel's
@@ -1090,9 +1220,46 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
         const float dr = q0 / sc - mr * mr, dg = q1 / sc - mg_ * mg_, db = q2 / sc - mb * mb;
         return dr < a.error && dg < a.error && db < a.error;
     };
-    bool lowvar = false;
-    if (in_image) lowvar = low_variance(lds.acc[0][lane], lds.acc[1][lane], lds.acc[2][lane], lds.acc[3][lane], lds.acc[4][lane],
-                                        lds.acc[5][lane], __float_as_int(lds.acc[6][lane]));
+    bool lowvar[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        lowvar[k] = false;
+        if constexpr (!kAccInLds) {
+            if (in_image[k]) {
+                const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + x[k];
+                lowvar[k] = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
+            }
+        } else {
+            const int id = lane + 64 * k;
+            if (in_image[k]) lowvar[k] = low_variance(lds.acc.v[0][id], lds.acc.v[1][id], lds.acc.v[2][id], lds.acc.v[3][id], lds.acc.v[4][id],
+                                                      lds.acc.v[5][id], __float_as_int(lds.acc.v[6][id]));
+        }
+    }
+    // adds one contribution (material.h:74-77) to pixel k of the lane and refreshes its cached adaptive-sampling answer
+    auto contribute = [&](int k, float cr, float cg, float cb) {
+        float n0, n1, n2, p0, p1, p2;
+        int nn;
+        if constexpr (!kAccInLds) {
+            // (the pixel's index is rebuilt from the lane number and the tile's wave-uniform corner, like the camera ray's x, y)
+            const uint32_t le = opaque(static_cast<uint32_t>(lane));
+            const size_t p = static_cast<size_t>(tile_y0 + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * k);
+            n0 = a.sum[3 * p] + cr; n1 = a.sum[3 * p + 1] + cg; n2 = a.sum[3 * p + 2] + cb;
+            p0 = a.sum2[3 * p] + cr * cr; p1 = a.sum2[3 * p + 1] + cg * cg; p2 = a.sum2[3 * p + 2] + cb * cb;
+            nn = a.count[p] + 1;
+            a.sum[3 * p] = n0; a.sum[3 * p + 1] = n1; a.sum[3 * p + 2] = n2;
+            a.sum2[3 * p] = p0; a.sum2[3 * p + 1] = p1; a.sum2[3 * p + 2] = p2;
+            a.count[p] = nn;
+        } else {
+            const int id = lane + 64 * k;   // the pixel's slot in the tile's accumulators
+            n0 = lds.acc.v[0][id] + cr; n1 = lds.acc.v[1][id] + cg; n2 = lds.acc.v[2][id] + cb;
+            p0 = lds.acc.v[3][id] + cr * cr; p1 = lds.acc.v[4][id] + cg * cg; p2 = lds.acc.v[5][id] + cb * cb;
+            nn = __float_as_int(lds.acc.v[6][id]) + 1;
+            lds.acc.v[0][id] = n0; lds.acc.v[1][id] = n1; lds.acc.v[2][id] = n2;
+            lds.acc.v[3][id] = p0; lds.acc.v[4][id] = p1; lds.acc.v[5][id] = p2;
+            lds.acc.v[6][id] = __int_as_float(nn);
+        }
+        lowvar[k] = low_variance(n0, n1, n2, p0, p1, p2, nn);
+    };
     // statistics are wave-level (uniform) counts: they live in SGPRs
     using Count = std::conditional_t<STATS, uint32_t, Ignored>;
     Count n_traced = 0, n_segments = 0, n_contrib = 0, n_miss = 0;
@@ -1106,70 +1273,102 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
 #ifdef PT_VERIFY_SHIPPED
     uint32_t v_checked = 0, v_bad = 0;   // wave-uniform
 #endif
+    auto any_of = [&](const bool (&b)[R]) {   // wave-uniform: any ray of the wave
+        bool v = b[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k) v = v || b[k];
+        return __any(v);
+    };
 
     for (int pass = pass_first; pass < pass_last; ++pass) {
         // Adaptive skip, main.cpp:118-125.
-        const bool skip = !in_image || (pass > 10 && (pass % 4) && lowvar);
-        if (__all(skip)) continue;
+        bool skip[R], traced[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            skip[k] = !in_image[k] || (pass > 10 && (pass % 4) && lowvar[k]);
+            traced[k] = !skip[k];
+        }
+        if (!any_of(traced)) continue;
 
         // Primary ray, main.cpp:126-129 + Ray ctor ray.h:21-25 (double arithmetic, then narrowed).
-        Ray q;
-        float tr = 1.0f, tg = 1.0f, tb = 1.0f;   // Ray::color_ (throughput), ray.h:17
-        int depth = mrr;
-        if (!skip) {
-            uint32_t w0, w1, w2, w3;
-            philox4x32_10(opaque(gpix), static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
-            const double jx = jitter_double(w0), jy = jitter_double(w1);
-            // x, y are made opaque once per pass so that their int->double conversions (and the doubles of width and
-            // height) are redone here instead of being hoisted out of the pass loop, where they would occupy eight
-            // VGPRs for the whole kernel (the compiler spilled them to scratch: ~1 GB of memory traffic per frame).
-            // (x and y themselves are rebuilt from the lane number and the tile's wave-uniform corner: kept in two VGPRs for the
-            // whole kernel they were spilled to scratch, a launch-time cost that doubled the time of a 256 x 256 frame)
-            // (the big-scene kernel has the registers to keep them: there the recomputation costs 2.6 %)
-            int xi = x, yi = y;
-            if constexpr (!BIG) {
-                xi = tile_x0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) % kTileW);
-                yi = tile_y0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) / kTileW);
+        Ray q[R];
+        float tr[R], tg[R], tb[R];   // Ray::color_ (throughput), ray.h:17
+        int depth[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            tr[k] = tg[k] = tb[k] = 1.0f;
+            depth[k] = mrr;
+            if (!skip[k]) {
+                uint32_t w0, w1, w2, w3;
+                philox4x32_10(opaque(gpix[k]), static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
+                const double jx = jitter_double(w0), jy = jitter_double(w1);
+                // x, y are made opaque once per pass so that their int->double conversions (and the doubles of width and
+                // height) are redone here instead of being hoisted out of the pass loop, where they would occupy eight
+                // VGPRs for the whole kernel (the compiler spilled them to scratch: ~1 GB of memory traffic per frame).
+                // (x and y themselves are rebuilt from the lane number and the tile's wave-uniform corner: kept in two VGPRs for the
+                // whole kernel they were spilled to scratch, a launch-time cost that doubled the time of a 256 x 256 frame)
+                // (the big-scene kernel has the registers to keep them: there the recomputation costs 2.6 %)
+                int xi = x[k], yi = y;
+                if constexpr (!BIG) {
+                    xi = tile_x0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) % kTileW) + kTileW * k;
+                    yi = tile_y0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) / kTileW);
+                }
+                int wi = a.width, hi = a.height;
+                asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
+                q[k].dx = static_cast<float>((xi + jx) / wi - 0.5f);
+                q[k].dy = static_cast<float>(-(yi + jy) / hi + 0.5f);
+                q[k].dz = 1.0f;
+                const float inv = rcp_rn_normal(sqrt_rn_normal((q[k].dx * q[k].dx + q[k].dy * q[k].dy) + (1.0f * 1.0f + 0.0f * 0.0f)));   // 1 <= argument < 2
+                q[k].dx = q[k].dx * inv; q[k].dy = q[k].dy * inv; q[k].dz = q[k].dz * inv;
+                q[k].ox = 0.0f; q[k].oy = 0.0f; q[k].oz = -20.0f;
+                depth[k] = 0;
+            } else {
+                q[k].ox = q[k].oy = q[k].oz = 0.0f; q[k].dx = q[k].dy = 0.0f; q[k].dz = 1.0f;
             }
-            int wi = a.width, hi = a.height;
-            asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
-            q.dx = static_cast<float>((xi + jx) / wi - 0.5f);
-            q.dy = static_cast<float>(-(yi + jy) / hi + 0.5f);
-            q.dz = 1.0f;
-            const float inv = rcp_rn_normal(sqrt_rn_normal((q.dx * q.dx + q.dy * q.dy) + (1.0f * 1.0f + 0.0f * 0.0f)));   // 1 <= argument < 2
-            q.dx = q.dx * inv; q.dy = q.dy * inv; q.dz = q.dz * inv;
-            q.ox = 0.0f; q.oy = 0.0f; q.oz = -20.0f;
-            depth = 0;
-        } else {
-            q.ox = q.oy = q.oz = 0.0f; q.dx = q.dy = 0.0f; q.dz = 1.0f;
+            if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(!skip[k]));
         }
 
-        if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(!skip));
-
         for (;;) {
-            const bool valid = depth < mrr && (tr != 0.0f || tg != 0.0f || tb != 0.0f);   // Ray::IsValid, ray.h:52-54
-            if (!__any(valid)) break;
-            if constexpr (STATS) n_segments += __builtin_popcountll(__ballot(valid));
+            bool valid[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) valid[k] = depth[k] < mrr && (tr[k] != 0.0f || tg[k] != 0.0f || tb[k] != 0.0f);   // Ray::IsValid, ray.h:52-54
+            if (!any_of(valid)) break;
+            if constexpr (STATS) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) n_segments += __builtin_popcountll(__ballot(valid[k]));
+            }
 
-            float best;
-            int hit;
-            const ExactRec *hit_rec;
+            float best[R];
+            int hit[R];
+            const ExactRec *hit_rec[R];
             // The culling margins hold for origins within r_org of the scene (pt_scene.cpp).  A path can leave that envelope:
             // the reference accepts a near-degenerate triangle for points that have nothing to do with it, at any distance
             // (all three computed sub-areas can vanish), and the next segment then starts millions of units away.  For such
             // a ray nothing is culled: every triangle goes through the exact test.  (A NaN origin counts as outside.)
             // (one v_max3_f32 with |.| modifiers and one compare; an origin here is never NaN: it is o + d t + N eps of finite terms)
-            bool inside = true;
-            if constexpr (ENV)
-                inside = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q.ox), __builtin_fabsf(q.oy)), __builtin_fabsf(q.oz)) <= a.r_org;
-            // A path's last segment (depth + 1 == mrr; the live lanes of a wave reach it together) can only contribute by hitting
+            bool inside[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                inside[k] = true;
+                if constexpr (ENV)
+                    inside[k] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(q[k].ox), __builtin_fabsf(q[k].oy)), __builtin_fabsf(q[k].oz)) <= a.r_org;
+            }
+            // A path's last segment (depth + 1 == mrr; the live rays of a wave reach it together) can only contribute by hitting
             // an emitter, and whatever else it hits is never looked at (no next ray, statistics not requested, no skybox).  So
             // the search runs among the emitters alone first -- for Tor.obj one quad record instead of seven walls and a torus --
             // and the full search, which decides whether the emitter really is the closest hit, only for rays that hit one.
-            bool searched = valid;
+            bool searched[R], last_or_dead[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                searched[k] = valid[k];
+                last_or_dead[k] = !valid[k] || depth[k] + 1 >= mrr;
+            }
+            bool all_last = last_or_dead[0];
+#pragma unroll
+            for (int k = 1; k < R; ++k) all_last = all_last && last_or_dead[k];
             constexpr bool kLastSegmentFilter = !STATS && !SKY && !BIG;   // (big scenes: the flag's scalar registers cost more than it saves)
             bool emis_phase = false;
-            if constexpr (kLastSegmentFilter) emis_phase = a.last_segment_filter != 0u && __all(!valid || depth + 1 >= mrr);
+            if constexpr (kLastSegmentFilter) emis_phase = a.last_segment_filter != 0u && __all(all_last);
 #ifdef PT_VERIFY_SHIPPED
             bool filtered_last = emis_phase;   // wave-uniform: this segment's search only has to find emitters
 #endif
@@ -1177,7 +1376,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                 // Big scenes: the same idea without a second search.  The table builder keeps a big scene's emitters in the
                 // large class (pt_scene.cpp), so the conservative test of those records alone says which rays of the last
                 // segment can reach an emitter at all; only those are searched.
-                if (a.last_segment_filter != 0u && a.emis_bvh == 0u && a.n_clusters == 1 && __all(!valid || depth + 1 >= mrr)) {
+                if (a.last_segment_filter != 0u && a.emis_bvh == 0u && a.n_clusters == 1 && __all(all_last)) {
                     const ConstF cp = (ConstF)reinterpret_cast<uintptr_t>(a.clusters) + (sizeof(ClusterDesc) / 4) * (a.n_clusters - 1);
                     const uint32_t n_large = ((ConstU)cp)[5], kind = ((ConstU)cp)[6], off = ((ConstU)cp)[7], quads = ((ConstU)cp)[9];
                     if (kind == 1u && n_large <= static_cast<uint32_t>(kChunk)) {
@@ -1188,15 +1387,15 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                         for (uint32_t rest = (a.emis_large_w0 | (a.emis_large_w0 >> 1)) & 0x55555555u; rest != 0; rest &= rest - 1) {
                             const uint32_t k0 = __builtin_ctz(rest);
                             if ((quads >> k0) & 1u) {
-                                m |= (~cull_reject_quad(load_cull(bp + 12 * k0), q, k1, k2, a_max, m0q, t_guard) & 3u) << k0;
+                                m |= (~cull_reject_quad(load_cull(bp + 12 * k0), q[0], k1, k2, a_max, m0q, t_guard) & 3u) << k0;
                             } else {
                                 for (uint32_t j = 0; j < 2; ++j)
-                                    m |= cull_reject(load_cull(bp + 12 * (k0 + j)), q, k1, k2, a_max, m0, t_guard) ? 0u : (1u << (k0 + j));
+                                    m |= cull_reject(load_cull(bp + 12 * (k0 + j)), q[0], k1, k2, a_max, m0, t_guard) ? 0u : (1u << (k0 + j));
                             }
                         }
                         bool can_reach = (m & a.emis_large_w0) != 0u;
-                        if constexpr (ENV) can_reach = can_reach || !inside;   // (outside the margins' envelope nothing is culled)
-                        searched = valid && can_reach;
+                        if constexpr (ENV) can_reach = can_reach || !inside[0];   // (outside the margins' envelope nothing is culled)
+                        searched[0] = valid[0] && can_reach;
 #ifdef PT_VERIFY_SHIPPED
                         filtered_last = true;
 #endif
@@ -1204,14 +1403,17 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                 }
             }
             for (;;) {
-                if (BIG && !__any(searched)) break;
+                if (BIG && !any_of(searched)) break;
                 closest_hit<ENV, kLastSegmentFilter>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase);
                 if (!emis_phase) break;
                 emis_phase = false;
-                searched = searched && hit >= 0;
-                if (!__any(searched)) break;
+#pragma unroll
+                for (int k = 0; k < R; ++k) searched[k] = searched[k] && hit[k] >= 0;
+                if (!any_of(searched)) break;
             }
-            if (!searched) hit = -1;   // (a ray of the last segment that met no emitter ends like a miss, contributing nothing)
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (!searched[k]) hit[k] = -1;   // (a ray of the last segment that met no emitter ends like a miss, contributing nothing)
 #ifdef PT_VERIFY_SHIPPED
             // Verification of the path that SHIPS (libpt_verify_shipped.so, never the product): this is the statistics-free
             // instantiation with the emitter-first last segment and the big scenes' can-reach filter compiled in.  Every segment's
@@ -1219,9 +1421,10 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
             // (distance bits, triangle index) -- except that a FILTERED last segment may report a miss where the reference hits
             // something, if and only if that something has no emissive lobe (nothing else of a last segment is ever looked at:
             // Ray::IsValid ray.h:52-54, material.h:67-80).
-            {
-                const unsigned long long brute = brute_force_key(a, q, eps);
-                const unsigned long long mine = hit < 0 ? ~0ull : ((static_cast<unsigned long long>(ordered_bits(best)) << 32) | static_cast<uint32_t>(hit));
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const unsigned long long brute = brute_force_key(a, q[k], eps);
+                const unsigned long long mine = hit[k] < 0 ? ~0ull : ((static_cast<unsigned long long>(ordered_bits(best[k])) << 32) | static_cast<uint32_t>(hit[k]));
                 bool ok = brute == mine;
                 if (!ok && filtered_last && mine == ~0ull) {
                     bool emissive = false;
@@ -1231,27 +1434,29 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                     }
                     ok = !emissive;
                 }
-                v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid)));
-                v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid && !ok)));
-                if (valid && !ok && a.stats) {   // one example for the host to print (any of them)
+                v_checked += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid[k])));
+                v_bad += static_cast<uint32_t>(__builtin_popcountll(__ballot(valid[k] && !ok)));
+                if (valid[k] && !ok && a.stats) {   // one example for the host to print (any of them)
                     a.stats[11] = brute;
                     a.stats[12] = mine;
-                    a.stats[13] = (static_cast<unsigned long long>(__float_as_uint(q.ox)) << 32) | __float_as_uint(q.oy);
-                    a.stats[14] = (static_cast<unsigned long long>(__float_as_uint(q.oz)) << 32) | __float_as_uint(q.dx);
-                    a.stats[15] = (static_cast<unsigned long long>(__float_as_uint(q.dy)) << 32) | __float_as_uint(q.dz);
+                    a.stats[13] = (static_cast<unsigned long long>(__float_as_uint(q[k].ox)) << 32) | __float_as_uint(q[k].oy);
+                    a.stats[14] = (static_cast<unsigned long long>(__float_as_uint(q[k].oz)) << 32) | __float_as_uint(q[k].dx);
+                    a.stats[15] = (static_cast<unsigned long long>(__float_as_uint(q[k].dy)) << 32) | __float_as_uint(q[k].dz);
                 }
             }
 #endif
 
-            // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50)
-            if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid && hit < 0));
+            // ---- 3. shade (Scene::TraceRay scene.cpp:121-156, Material::Process material.h:36-50), ray after ray of the lane
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+            if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid[k] && hit[k] < 0));
             bool contributed = false;
-            if (valid) {
-                if (hit < 0) {
+            if (valid[k]) {
+                if (hit[k] < 0) {
                     if (SKY) {   // skybox miss shader, scene.cpp:126-154 (note: the path throughput is NOT applied)
                         const float pi = 3.141593f;
-                        const float theta = portable_acosf(q.dy) / pi;
-                        const float phi = portable_atan2f(q.dz, -q.dx) / pi / 2 + 0.5f;
+                        const float theta = portable_acosf(q[k].dy) / pi;
+                        const float phi = portable_atan2f(q[k].dz, -q[k].dx) / pi / 2 + 0.5f;
                         const uint32_t sw = static_cast<uint32_t>(a.sky_w), sh = static_cast<uint32_t>(a.sky_h);
                         const float sx = phi * static_cast<float>(sw), sy = theta * static_cast<float>(sh);
                         // float -> unsigned is undefined for NaN / out of range in the reference; clamp into the image
@@ -1265,36 +1470,30 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                         const float ax = 1 - sx + static_cast<float>(x1), ay = 1 - sy + static_cast<float>(y1);
                         float c[3];
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {   // r,g,b = bytes 2,1,0
-                            const float c1 = static_cast<float>(t1[2 - k]), c2 = static_cast<float>(t2[2 - k]);
-                            const float c3 = static_cast<float>(t3[2 - k]), c4 = static_cast<float>(t4[2 - k]);
+                        for (int ch = 0; ch < 3; ++ch) {   // r,g,b = bytes 2,1,0
+                            const float c1 = static_cast<float>(t1[2 - ch]), c2 = static_cast<float>(t2[2 - ch]);
+                            const float c3 = static_cast<float>(t3[2 - ch]), c4 = static_cast<float>(t4[2 - ch]);
                             const float c12 = c1 * (1.0f - ax) + c2 * ax;   // glm::mix(x, y, a) = x*(1-a) + y*a
                             const float c34 = c3 * (1.0f - ax) + c4 * ax;
-                            c[k] = (c12 * (1.0f - ay) + c34 * ay) / 256.f;
+                            c[ch] = (c12 * (1.0f - ay) + c34 * ay) / 256.f;
                         }
-                        const float n0 = lds.acc[0][lane] + c[0], n1 = lds.acc[1][lane] + c[1], n2 = lds.acc[2][lane] + c[2];
-                        const float p0 = lds.acc[3][lane] + c[0] * c[0], p1 = lds.acc[4][lane] + c[1] * c[1], p2 = lds.acc[5][lane] + c[2] * c[2];
-                        const int nn = __float_as_int(lds.acc[6][lane]) + 1;
-                        lds.acc[0][lane] = n0; lds.acc[1][lane] = n1; lds.acc[2][lane] = n2;
-                        lds.acc[3][lane] = p0; lds.acc[4][lane] = p1; lds.acc[5][lane] = p2;
-                        lds.acc[6][lane] = __int_as_float(nn);
-                        lowvar = low_variance(n0, n1, n2, p0, p1, p2, nn);
+                        contribute(k, c[0], c[1], c[2]);
                         contributed = true;
                     }
-                    depth = mrr;   // MakeInvalid
+                    depth[k] = mrr;   // MakeInvalid
                 } else {
-                    const ExactRec *__restrict__ rec = hit_rec;
+                    const ExactRec *__restrict__ rec = hit_rec[k];
                     const float4 pl = reinterpret_cast<const float4 *>(rec)[0];
                     const int mi = rec->material;
-                    const float px = q.ox + q.dx * best, py = q.oy + q.dy * best, pz = q.oz + q.dz * best;
+                    const float px = q[k].ox + q[k].dx * best[k], py = q[k].oy + q[k].dy * best[k], pz = q[k].oz + q[k].dz * best[k];
                     const float4 m0v = reinterpret_cast<const float4 *>(a.mats + mi)[0];   // kd, chance0
                     const float4 m1v = reinterpret_cast<const float4 *>(a.mats + mi)[1];   // ks, chance1
                     const int4 m2v = reinterpret_cast<const int4 *>(a.mats + mi)[2];       // n_lobes, kind0, kind1
                     // On a path's last segment the random words only matter where they choose between an emissive lobe and
                     // another one (see below: nothing else of that segment survives it).
                     uint32_t w0 = 0, w1 = 0, w2 = 0, w3;
-                    if (depth + 1 < mrr || (m2v.x >= 2 && (m2v.y == 0 || m2v.z == 0)))
-                        philox4x32_10(opaque(gpix), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth), 0u, a.seed, kPhiloxKey1,
+                    if (depth[k] + 1 < mrr || (m2v.x >= 2 && (m2v.y == 0 || m2v.z == 0)))
+                        philox4x32_10(opaque(gpix[k]), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth[k]), 0u, a.seed, kPhiloxKey1,
                                       w0, w1, w2, w3);
                     int kind;
                     if (m2v.x == 0) {
@@ -1308,31 +1507,25 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                         kind = (sample - m0v.w > 0) ? m2v.z : m2v.y;
                     }
                     if (kind < 0) {
-                        depth = mrr;
+                        depth[k] = mrr;
                     } else if (kind == 0) {   // emissive, material.h:68-79
-                        if (!((q.dx * pl.x + q.dy * pl.y) + q.dz * pl.z > 0)) {
-                            const float cr = tr * m0v.x, cg = tg * m0v.y, cb = tb * m0v.z;
-                            const float n0 = lds.acc[0][lane] + cr, n1 = lds.acc[1][lane] + cg, n2 = lds.acc[2][lane] + cb;
-                            const float p0 = lds.acc[3][lane] + cr * cr, p1 = lds.acc[4][lane] + cg * cg, p2 = lds.acc[5][lane] + cb * cb;
-                            const int nn = __float_as_int(lds.acc[6][lane]) + 1;
-                            lds.acc[0][lane] = n0; lds.acc[1][lane] = n1; lds.acc[2][lane] = n2;
-                            lds.acc[3][lane] = p0; lds.acc[4][lane] = p1; lds.acc[5][lane] = p2;
-                            lds.acc[6][lane] = __int_as_float(nn);
-                            lowvar = low_variance(n0, n1, n2, p0, p1, p2, nn);
+                        if (!((q[k].dx * pl.x + q[k].dy * pl.y) + q[k].dz * pl.z > 0)) {
+                            const float cr = tr[k] * m0v.x, cg = tg[k] * m0v.y, cb = tb[k] * m0v.z;
+                            contribute(k, cr, cg, cb);
                             contributed = true;
                         }
-                        depth = mrr;
+                        depth[k] = mrr;
                     } else {
                         // Both scattering lobes end in Ray::Reflect (ray.h:45-50): the lobe-specific part leaves the new direction
                         // (not yet normalised by Reflect) and the throughput factor, the common tail runs once per wave.
                         // A path's last segment (depth + 1 == mrr: all live lanes of a wave reach it together) can only contribute
                         // through the emissive lobe above: the ray a scattering lobe would produce is never traced
                         // (Ray::IsValid, ray.h:52-54), so it is not computed either.
-                        if (depth + 1 < mrr) {
+                        if (depth[k] + 1 < mrr) {
                         float rx, ry, rz, fr, fg, fb;
                         if (kind == 1) {   // glossy, material.h:83-85
-                            const float dn = (pl.x * q.dx + pl.y * q.dy) + pl.z * q.dz;
-                            rx = q.dx - pl.x * dn * 2.0f; ry = q.dy - pl.y * dn * 2.0f; rz = q.dz - pl.z * dn * 2.0f;
+                            const float dn = (pl.x * q[k].dx + pl.y * q[k].dy) + pl.z * q[k].dz;
+                            rx = q[k].dx - pl.x * dn * 2.0f; ry = q[k].dy - pl.y * dn * 2.0f; rz = q[k].dz - pl.z * dn * 2.0f;
                             fr = m1v.x; fg = m1v.y; fb = m1v.z;
                         } else {   // diffuse, material.h:90-100
                             const float xi1 = unit_float(w1), xi2 = unit_float(w2);
@@ -1348,63 +1541,77 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : STATS ? PT_WA
                             fr = m0v.x * dt; fg = m0v.y * dt; fb = m0v.z * dt;
                         }
                         normalize3(rx, ry, rz);   // Ray::Reflect normalises (again), ray.h:47
-                        q.ox = px + pl.x * eps; q.oy = py + pl.y * eps; q.oz = pz + pl.z * eps;
-                        q.dx = rx; q.dy = ry; q.dz = rz;
-                        tr *= fr; tg *= fg; tb *= fb;
+                        q[k].ox = px + pl.x * eps; q[k].oy = py + pl.y * eps; q[k].oz = pz + pl.z * eps;
+                        q[k].dx = rx; q[k].dy = ry; q[k].dz = rz;
+                        tr[k] *= fr; tg[k] *= fg; tb[k] *= fb;
                         }
-                        ++depth;
+                        ++depth[k];
                     }
                 }
             }
             if constexpr (STATS) n_contrib += __builtin_popcountll(__ballot(contributed));
+            }
             PT_STAMP(wst, 7);   // shading
         }
     }
 
-    // Write-back.  A tile whose rows are 16-byte aligned in the caller's planes is written with one 16-byte store per lane
-    // (a row of the tile is kTileW*12 contiguous bytes of sum / sum2 and kTileW*4 of count): dword stores at a 12-byte
-    // stride made the memory side see about twice the bytes.
-    const int tile_x = static_cast<int>(tile % a.blocks_x) * kTileW, tile_y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;
-    const bool whole = a.vec_ok && tile_x + kTileW <= a.width && tile_y + kTileH <= a.row_end;   // wave-uniform
+    // Write-back.  A tile whose rows are 16-byte aligned in the caller's planes is written with 16-byte stores (a row of
+    // the tile is kTW*12 contiguous bytes of sum / sum2 and kTW*4 of count): dword stores at a 12-byte stride made the
+    // memory side see about twice the bytes.  Column c of the tile's row r lives in LDS slot r*kTileW + c%kTileW + 64*(c/kTileW).
+    if constexpr (kAccInLds) {
+    const int tile_x = static_cast<int>(tile % a.blocks_x) * kTW, tile_y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;
+    const bool whole = a.vec_ok && tile_x + kTW <= a.width && tile_y + kTileH <= a.row_end;   // wave-uniform
     wave_sync();
+    auto slot_of = [](int row, int col) { return row * kTileW + (col % kTileW) + 64 * (col / kTileW); };
     if (whole) {
-        constexpr int kRowVec = kTileW * 3 / 4;          // float4 per tile row of a colour plane
-        if (lane < kRowVec * kTileH) {
-            const int row = lane / kRowVec, v = lane % kRowVec;
-            const size_t base = (static_cast<size_t>(tile_y - a.row_begin + row) * a.width + tile_x) * 3 + 4 * v;
-            float4 o1, o2;
-            float *p1 = &o1.x, *p2 = &o2.x;
+        constexpr int kRowVec = kTW * 3 / 4;          // float4 per tile row of a colour plane
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = 4 * v + j;                   // element of the row: pixel e/3, channel e%3
-                p1[j] = lds.acc[e % 3][row * kTileW + e / 3];
-                p2[j] = lds.acc[3 + e % 3][row * kTileW + e / 3];
+        for (int v0 = 0; v0 < kRowVec * kTileH; v0 += kBlock) {
+            const int vv = v0 + lane;
+            if (vv < kRowVec * kTileH) {
+                const int row = vv / kRowVec, v = vv % kRowVec;
+                const size_t base = (static_cast<size_t>(tile_y - a.row_begin + row) * a.width + tile_x) * 3 + 4 * v;
+                float4 o1, o2;
+                float *p1 = &o1.x, *p2 = &o2.x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * v + j;                   // element of the row: pixel e/3, channel e%3
+                    p1[j] = lds.acc.v[e % 3][slot_of(row, e / 3)];
+                    p2[j] = lds.acc.v[3 + e % 3][slot_of(row, e / 3)];
+                }
+                *reinterpret_cast<float4 *>(a.sum + base) = o1;
+                *reinterpret_cast<float4 *>(a.sum2 + base) = o2;
             }
-            *reinterpret_cast<float4 *>(a.sum + base) = o1;
-            *reinterpret_cast<float4 *>(a.sum2 + base) = o2;
         }
-        constexpr int kCntVec = kTileW / 4;              // int4 per tile row of the count plane
+        constexpr int kCntVec = kTW / 4;              // int4 per tile row of the count plane
         if (lane < kCntVec * kTileH) {
             const int row = lane / kCntVec, v = lane % kCntVec;
             const size_t base = static_cast<size_t>(tile_y - a.row_begin + row) * a.width + tile_x + 4 * v;
             int4 oc;
-            oc.x = __float_as_int(lds.acc[6][row * kTileW + 4 * v]);
-            oc.y = __float_as_int(lds.acc[6][row * kTileW + 4 * v + 1]);
-            oc.z = __float_as_int(lds.acc[6][row * kTileW + 4 * v + 2]);
-            oc.w = __float_as_int(lds.acc[6][row * kTileW + 4 * v + 3]);
+            oc.x = __float_as_int(lds.acc.v[6][slot_of(row, 4 * v)]);
+            oc.y = __float_as_int(lds.acc.v[6][slot_of(row, 4 * v + 1)]);
+            oc.z = __float_as_int(lds.acc.v[6][slot_of(row, 4 * v + 2)]);
+            oc.w = __float_as_int(lds.acc.v[6][slot_of(row, 4 * v + 3)]);
             *reinterpret_cast<int4 *>(a.count + base) = oc;
         }
-    } else if (in_image) {
+    } else {
         // recomputed from the tile's corner and the lane number: p, x or y kept across the kernel would be spilled
         const uint32_t le = opaque(static_cast<uint32_t>(lane));
-        const size_t pe = BIG ? static_cast<size_t>(y - a.row_begin) * a.width + x
-                              : static_cast<size_t>(tile_y + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x + static_cast<int>(le % kTileW));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            a.sum[3 * pe + k] = lds.acc[k][lane];
-            a.sum2[3 * pe + k] = lds.acc[3 + k][lane];
+        for (int k = 0; k < R; ++k) {
+            const int xe = tile_x + static_cast<int>(le % kTileW) + kTileW * k, ye = tile_y + static_cast<int>(le / kTileW);
+            if (xe < a.width && ye < a.row_end) {
+                const size_t pe = static_cast<size_t>(ye - a.row_begin) * a.width + xe;
+                const int id = lane + 64 * k;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a.sum[3 * pe + c] = lds.acc.v[c][id];
+                    a.sum2[3 * pe + c] = lds.acc.v[3 + c][id];
+                }
+                a.count[pe] = __float_as_int(lds.acc.v[6][id]);
+            }
         }
-        a.count[pe] = __float_as_int(lds.acc[6][lane]);
+    }
     }
     if (chunk + 1 < a.n_chunks) {   // publish the tile's accumulators to the wave that takes its next chunk
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1443,7 +1650,7 @@ template <bool BIG>
 __global__ __launch_bounds__(kBlock, BIG ? PT_BIG_WAVES : PT_WAVES_PER_SIMD) void trace_rays_kernel(const RenderArgs a, const float *__restrict__ origins,
                                                                               const float *__restrict__ directions, int n_rays,
                                                                               int32_t *__restrict__ hit_index, float *__restrict__ hit_t) {
-    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>> lds;
+    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, SmallQueues>, 1> lds;
     const int lane = threadIdx.x;
     const int i = blockIdx.x * kBlock + lane;
     const bool valid = i < n_rays;
@@ -1458,14 +1665,16 @@ __global__ __launch_bounds__(kBlock, BIG ? PT_BIG_WAVES : PT_WAVES_PER_SIMD) voi
     const float d2 = (q.dx * q.dx + q.dy * q.dy) + q.dz * q.dz;
     const bool inside = __builtin_fabsf(q.ox) <= a.r_org && __builtin_fabsf(q.oy) <= a.r_org && __builtin_fabsf(q.oz) <= a.r_org &&
                         __builtin_fabsf(d2 - 1.0f) <= 1.0e-5f;
-    float best;
-    int hit;
-    const ExactRec *hit_rec;
+    float best[1];
+    int hit[1];
+    const ExactRec *hit_rec[1];
     WaveStats st;
-    closest_hit<true, false>(a, lds, q, valid, inside, lane, a.eps, best, hit, hit_rec, st);
+    const Ray qs[1] = {q};
+    const bool lives[1] = {valid}, insides[1] = {inside};
+    closest_hit<true, false>(a, lds, qs, lives, insides, lane, a.eps, best, hit, hit_rec, st);
     if (valid) {
-        hit_index[i] = hit;
-        hit_t[i] = best;
+        hit_index[i] = hit[0];
+        hit_t[i] = best[0];
     }
 }
 
@@ -1543,19 +1752,28 @@ hipError_t integrator_waves_per_cu(const RenderArgs &, int *waves) {
     *waves = 24;
     return hipSuccess;
 }
+int integrator_tile_width(const RenderArgs &args) {
+    return kTileW * ((!args.sky && args.n_tri <= kBigSceneTriangles && !args.stats) ? PT_RAYS_PER_LANE : 1);
+}
 #else
 namespace {
+// statistics instantiation or not, for a launch with these arguments
+bool launch_with_stats(const RenderArgs &args) {
+#if defined(PT_PHASE_TIMERS) || defined(PT_VERIFY_BRUTE)
+    (void)args;
+    return true;
+#elif defined(PT_VERIFY_SHIPPED)
+    (void)args;
+    return false;   // the instantiations a caller without pt_render_stats gets; args.stats only receives the verdict
+#else
+    return args.stats != nullptr;
+#endif
+}
 // Calls f(kernel) with the instantiation a launch with these arguments runs.
 template <class F>
 void with_instantiation(const RenderArgs &args, F &&f) {
     const bool big = args.n_tri > kBigSceneTriangles;
-#if defined(PT_PHASE_TIMERS) || defined(PT_VERIFY_BRUTE)
-    const bool stats = true;
-#elif defined(PT_VERIFY_SHIPPED)
-    const bool stats = false;   // the instantiations a caller without pt_render_stats gets; args.stats only receives the verdict
-#else
-    const bool stats = args.stats != nullptr;
-#endif
+    const bool stats = launch_with_stats(args);
     auto pick = [&](auto sky, auto bg, auto st) {
         constexpr bool S = decltype(sky)::value, B = decltype(bg)::value, T = decltype(st)::value;
         if (args.may_leave_envelope) f(integrate_kernel<S, B, T, true>, ((S * 2 + B) * 2 + T) * 2 + 1);
@@ -1583,6 +1801,13 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     const unsigned grid = args.n_tiles * args.n_chunks;
     with_instantiation(args, [&](auto kernel, int) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args); });
     return hipGetLastError();
+}
+
+// Width in pixels of the tile one wave of that instantiation owns (its height is kTileH): RenderArgs::blocks_x and n_tiles
+// count tiles of this width.
+int integrator_tile_width(const RenderArgs &args) {
+    const bool sky = args.sky != nullptr, big = args.n_tri > kBigSceneTriangles, stats = launch_with_stats(args);
+    return kTileW * ((!sky && !big && !stats) ? PT_RAYS_PER_LANE : 1);
 }
 
 // Waves (= workgroups: one wave each) of that instantiation one compute unit holds at a time, from the runtime's occupancy
