@@ -15,6 +15,7 @@
 
 #ifdef PT_TEST_HOOKS
 static int g_items_per_slot = 0;
+static int g_force_tile_width = 0;   // 1 = always 8 x 8 tiles, 2 = always the widest the instantiation has, 0 = by tile count
 #endif
 
 namespace ptc {
@@ -259,9 +260,12 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
         a.stats = ctx.d_stats;
     }
     // one wave = one tile of 8 rows; how many pixels wide depends on the instantiation this launch runs
-    const int tile_w = pt::integrator_tile_width(a);
-    a.blocks_x = (p->width + tile_w - 1) / tile_w;
-    const uint32_t n_tiles = static_cast<uint32_t>(a.blocks_x) * static_cast<uint32_t>((p->row_end - p->row_begin + pt::kTileH - 1) / pt::kTileH);
+#ifdef PT_TEST_HOOKS
+    pt::integrator_plan_tiles(a, scene->cu_count, g_force_tile_width);
+#else
+    pt::integrator_plan_tiles(a, scene->cu_count);
+#endif
+    const uint32_t n_tiles = a.n_tiles;
     // Scheduler: cut the pass range into chunks so that the tail of the launch is balanced with small work items.  A tile's
     // chunks run in order and each re-reads and re-writes the tile's accumulators, so there should be few of them: chunk c
     // takes 3/4 of the passes that are left (256 passes: 192 + 48 + 16), the last one at least 4 and less than 32.
@@ -1042,7 +1046,7 @@ int pt_test_set_mutation(const char *family, double value) {
     if (!family) return PT_ERR_INVALID_ARGUMENT;
     const std::string f = family;
     pt::CullMutation &m = pt::g_cull_mutation;
-    if (f == "reset") { m = pt::CullMutation(); g_items_per_slot = 0; }
+    if (f == "reset") { m = pt::CullMutation(); g_items_per_slot = 0; g_force_tile_width = 0; }
     else if (f == "sphere_r2") m.sphere_r2 = value;
     else if (f == "m0") m.m0 = value;
     else if (f == "k12") m.k12 = value;
@@ -1056,6 +1060,7 @@ int pt_test_set_mutation(const char *family, double value) {
     else if (f == "order_mode") m.order_mode = static_cast<int>(value);
     else if (f == "bvh_fill") m.bvh_fill = value;
     else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);
+    else if (f == "tile_width") g_force_tile_width = static_cast<int>(value);
     else return fail(PT_ERR_INVALID_ARGUMENT, "unknown mutation family " + f);
     return PT_OK;
 }

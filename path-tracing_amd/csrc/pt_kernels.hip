@@ -1136,9 +1136,12 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 template <bool SKY, bool BIG, bool STATS>
 constexpr int rays_per_lane() { return (!SKY && !BIG && !STATS) ? PT_RAYS_PER_LANE : 1; }
 
-template <bool SKY, bool BIG, bool STATS, bool ENV>
-__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || rays_per_lane<SKY, BIG, STATS>() > 1) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
-    constexpr int R = rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
+// NARROW = the statistics-free small-scene kernel with ONE pixel per lane (8 x 8 tiles): for launches with too few pixels to
+// fill the chip with 16 x 8 tiles (small previews, thin row bands) -- half as many waves would leave wave slots empty.
+template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW = false>
+__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!NARROW && rays_per_lane<SKY, BIG, STATS>() > 1)) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+    static_assert(!NARROW || (!SKY && !BIG && !STATS), "only the statistics-free small-scene kernel has a narrow variant");
+    constexpr int R = NARROW ? 1 : rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
     constexpr int kTW = kTileW * R;
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R> lds;   // one wave per workgroup: all wave-private
 
@@ -1692,10 +1695,10 @@ hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, con
 #ifdef PT_BLOCK_PROFILE
 // the instantiations the instrumented code object must contain (nothing in this build references them)
 #define PT_INST(S, B) \
-    template __global__ void integrate_kernel<S, B, false, false>(const RenderArgs); \
-    template __global__ void integrate_kernel<S, B, true, false>(const RenderArgs);  \
-    template __global__ void integrate_kernel<S, B, false, true>(const RenderArgs);  \
-    template __global__ void integrate_kernel<S, B, true, true>(const RenderArgs);
+    template __global__ void integrate_kernel<S, B, false, false, false>(const RenderArgs); \
+    template __global__ void integrate_kernel<S, B, true, false, false>(const RenderArgs);  \
+    template __global__ void integrate_kernel<S, B, false, true, false>(const RenderArgs);  \
+    template __global__ void integrate_kernel<S, B, true, true, false>(const RenderArgs);
 PT_INST(false, false) PT_INST(false, true) PT_INST(true, false) PT_INST(true, true)
 #undef PT_INST
 }  // namespace pt
@@ -1726,7 +1729,7 @@ hipError_t launch_integrator(const RenderArgs &args0, hipStream_t stream) {
     RenderArgs args = args0;
     args.blockprof = d_cnt;
     char name[128];
-    std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dEEEvNS_10RenderArgsE", args.sky ? 1 : 0,
+    std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dELb0EEEvNS_10RenderArgsE", args.sky ? 1 : 0,
                   args.n_tri > kBigSceneTriangles ? 1 : 0, args.stats ? 1 : 0, args.may_leave_envelope ? 1 : 0);
     hipFunction_t f;
     e = hipModuleGetFunction(&f, mod, name);
@@ -1752,8 +1755,11 @@ hipError_t integrator_waves_per_cu(const RenderArgs &, int *waves) {
     *waves = 24;
     return hipSuccess;
 }
-int integrator_tile_width(const RenderArgs &args) {
-    return kTileW * ((!args.sky && args.n_tri <= kBigSceneTriangles && !args.stats) ? PT_RAYS_PER_LANE : 1);
+void integrator_plan_tiles(RenderArgs &args, int, int) {   // (the instrumented code object holds the wide variant only)
+    const int rays = (!args.sky && args.n_tri <= kBigSceneTriangles && !args.stats) ? PT_RAYS_PER_LANE : 1;
+    args.narrow = 0;
+    args.blocks_x = (args.width + kTileW * rays - 1) / (kTileW * rays);
+    args.n_tiles = static_cast<uint32_t>(args.blocks_x) * static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
 }
 #else
 namespace {
@@ -1776,6 +1782,13 @@ void with_instantiation(const RenderArgs &args, F &&f) {
     const bool stats = launch_with_stats(args);
     auto pick = [&](auto sky, auto bg, auto st) {
         constexpr bool S = decltype(sky)::value, B = decltype(bg)::value, T = decltype(st)::value;
+        if constexpr (!S && !B && !T) {
+            if (args.narrow) {
+                if (args.may_leave_envelope) f(integrate_kernel<false, false, false, true, true>, 17);
+                else f(integrate_kernel<false, false, false, false, true>, 16);
+                return;
+            }
+        }
         if (args.may_leave_envelope) f(integrate_kernel<S, B, T, true>, ((S * 2 + B) * 2 + T) * 2 + 1);
         else f(integrate_kernel<S, B, T, false>, ((S * 2 + B) * 2 + T) * 2);
     };
@@ -1803,18 +1816,34 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Width in pixels of the tile one wave of that instantiation owns (its height is kTileH): RenderArgs::blocks_x and n_tiles
-// count tiles of this width.
-int integrator_tile_width(const RenderArgs &args) {
+// Cuts the launch's row band into the tiles of the instantiation it will run: fills narrow, blocks_x, n_tiles.  The
+// statistics-free small-scene kernel owns 16 x 8 tiles (two pixels per lane) -- unless that would leave the chip's wave slots
+// underfilled, in which case its 8 x 8 variant runs (a tile's passes are a serial chain: fewer tiles than slots means idle SIMDs).
+void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
     const bool sky = args.sky != nullptr, big = args.n_tri > kBigSceneTriangles, stats = launch_with_stats(args);
-    return kTileW * ((!sky && !big && !stats) ? PT_RAYS_PER_LANE : 1);
+    const uint32_t rows = static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
+    int rays = (!sky && !big && !stats) ? PT_RAYS_PER_LANE : 1;
+    args.narrow = 0;
+    if (rays > 1) {
+        const uint32_t wide_tiles = static_cast<uint32_t>((args.width + kTileW * rays - 1) / (kTileW * rays)) * rows;
+        // one and a half rounds of its waves (measured, profiles/r03_ab_logs.txt ab53: 7 200 tiles -19 %, 8 160 tiles +3 %, 16 200 +6.6 %)
+        uint32_t min_tiles = static_cast<uint32_t>(cu_count) * 4u * static_cast<uint32_t>(PT_WAVES_PER_SIMD - 1) * 3u / 2u;
+        if (force == 1) min_tiles = 0xFFFFFFFFu;   // (test builds: always 8 x 8 / always 16 x 8)
+        if (force == 2) min_tiles = 0;
+        if (wide_tiles < min_tiles) {
+            rays = 1;
+            args.narrow = 1;
+        }
+    }
+    args.blocks_x = (args.width + kTileW * rays - 1) / (kTileW * rays);
+    args.n_tiles = static_cast<uint32_t>(args.blocks_x) * rows;
 }
 
 // Waves (= workgroups: one wave each) of that instantiation one compute unit holds at a time, from the runtime's occupancy
 // calculation (registers, LDS, launch bounds): the scheduler's count of wave slots.  Asked once per instantiation and device.
 hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves) {
     constexpr int kDevices = 16;
-    static std::atomic<int> cache[kDevices][16];   // 0 = not asked yet
+    static std::atomic<int> cache[kDevices][18];   // 0 = not asked yet
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

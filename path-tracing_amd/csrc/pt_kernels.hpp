@@ -35,6 +35,7 @@ struct RenderArgs {
     uint32_t seed;
     float k1, k2, a_max, m0, m0_quad, t_guard;   // cull margins (pt_scene.hpp: CullConstants)
     int32_t blocks_x;                   // ceil(width / tile width of the instantiation launched)
+    int32_t narrow;                     // 1: the statistics-free small-scene kernel runs its one-pixel-per-lane variant (8 x 8 tiles)
     uint32_t *sched;                    // [0] ticket counter, [1 + tile] chunks of that tile already published; zeroed per launch
     uint32_t n_tiles, n_chunks;         // work items = n_tiles * n_chunks, chunk-major
     int32_t chunk_passes;               // passes per chunk; 0 = geometric chunks (see the kernel)
@@ -53,8 +54,10 @@ struct RenderArgs {
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);
 // waves of the instantiation such a launch runs that one compute unit holds at a time (runtime occupancy query, cached)
 hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves);
-// width in pixels of the tile one wave of that instantiation owns: blocks_x and n_tiles of a launch count tiles of this width
-int integrator_tile_width(const RenderArgs &args);
+// cuts the launch's row band (width, row_begin, row_end, scene, stats already set) into the tiles of the instantiation it will
+// run: fills narrow, blocks_x and n_tiles
+// (force: 0 = by tile count, 1 = always 8 x 8 tiles, 2 = always the widest: test builds)
+void integrator_plan_tiles(RenderArgs &args, int cu_count, int force = 0);
 hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, const float *d_directions, int n_rays,
                              int32_t *d_hit_index, float *d_hit_t, hipStream_t stream);
 

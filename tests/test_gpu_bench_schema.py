@@ -62,7 +62,7 @@ def test_bench_emits_one_valid_json_line():
     assert 0 < rf["useful_fraction"] < rf["frac_active_lanes"] < rf["frac"]
     assert abs(rf["frac_active_lanes"] - rf["frac"] * rf["valu_active_lane_fraction"]) < 1e-9
     # the accuracy sample ran the instantiation the timed launches run
-    assert "false,false,false,false" in ac["gpu_instantiation"]
+    assert "false,false,false,false,false" in ac["gpu_instantiation"]
     # BASELINE configs[1] on fixed work, the reference-default adaptive run, configs[4] with its own counters: driver-timed
     assert j["configs1_64spp"]["value"] > 100.0 and "64 spp" in j["configs1_64spp"]["workload"]
     ad = j["adaptive_default"]
@@ -72,7 +72,7 @@ def test_bench_emits_one_valid_json_line():
     assert rep["x64"]["triangles"] == 16398 and rep["x195"]["triangles"] == 49934
     assert rep["x64"]["value"] > rep["x195"]["value"] > 100.0
     rb = rep["x64"]["roofline"]
-    assert rb["kernel"] == "pt::integrate_kernel<false,true,false,false>" and rb["achieved"] is not None, rb["counters_source"]
+    assert rb["kernel"] == "pt::integrate_kernel<false,true,false,false,false>" and rb["achieved"] is not None, rb["counters_source"]
     assert 0 < rb["useful_fraction"] < rb["frac_active_lanes"] < rb["frac"] <= 1.0
     assert 0.3 < rb["l1_hit_rate"] < 1.0 and rb["issue"]["instructions_per_wave_segment"] > 500
     assert rep["x64"]["node_rounds_per_wave_segment"] > 1

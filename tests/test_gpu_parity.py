@@ -59,6 +59,57 @@ def test_frame_bit_exact(gpu_scene, oracle_scene, W, H, spp, mrr, kw):
     assert st["exact_tests"] < 0.05 * st["segments"] * 270   # the cull really culls
 
 
+# The launches a caller WITHOUT pt_render_stats gets run another instantiation: two pixels per lane (16 x 8 tiles, 128 rays per
+# wave-segment, 7-bit ray ids in the work queues), accumulators read-modify-written in memory, the emitter-first last segment.
+# Same bar: the oracle's bits.  Widths around the 16-pixel tile, one-pixel images, adaptive sampling, and passes added in slices
+# (a later slice finds the earlier one's sums in memory).
+SHIPPED_CASES = [(1, 1, 40, 8, {}), (7, 3, 30, 8, {}), (8, 9, 20, 8, {}), (9, 8, 20, 3, {}), (15, 5, 16, 8, {}), (16, 8, 16, 8, {}),
+                 (17, 33, 8, 8, {"error": 0.001}), (31, 7, 12, 2, {}), (37, 19, 9, 8, {}), (96, 64, 6, 8, {}),
+                 (40, 24, 24, 8, {"error": 0.5}), (104, 50, 12, 8, {"error": 0.001, "seed": 7}), (250, 130, 5, 8, {"eps": 1e-3})]
+
+
+@pytest.fixture(scope="module")
+def hooks_lib():
+    L = pt.load_library(pt.TESTHOOKS_LIB_PATH)      # the product's kernels; its C API can pin the tile width (test hook)
+    L.pt_test_set_mutation(b"reset", 0.0)
+    yield L
+    L.pt_test_set_mutation(b"reset", 0.0)
+
+
+@pytest.mark.parametrize("W,H,spp,mrr,kw", SHIPPED_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}m{c[3]}{c[4]}" for c in SHIPPED_CASES])
+def test_statistics_free_instantiation_bit_exact(gpu_scene, oracle_scene, hooks_lib, models_dir, W, H, spp, mrr, kw):
+    rs, rs2, rc, _ = O.render(oracle_scene, W, H, spp, mrr, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, **kw)
+    # The library picks 16 x 8 tiles (two pixels per lane) only when they fill the chip, so frames of this size would run the
+    # 8 x 8 variant: both variants are pinned in turn through the test-hook build (same kernels), then the product's own choice.
+    for width_mode in (2.0, 1.0):
+        hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
+        try:
+            h = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=hooks_lib)
+            s, s2, c, _ = h.render_host(W, H, spp, mrr, want_stats=False, **kw)
+        finally:
+            hooks_lib.pt_test_set_mutation(b"reset", 0.0)
+        assert np.array_equal(c, rc) and _same(s, rs) and _same(s2, rs2), width_mode
+    hooks_lib.pt_test_set_mutation(b"tile_width", 2.0)      # the slices and the band below: the wide variant again
+    s, s2, c, _ = gpu_scene.render_host(W, H, spp, mrr, want_stats=False, **kw)
+    assert np.array_equal(c, rc) and _same(s, rs) and _same(s2, rs2)
+    gpu_scene = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=hooks_lib)
+    # the same frame in three pass slices on a device-resident session (odd slice lengths, a one-pass slice)
+    ses = pt.Session(gpu_scene, W, H)
+    cuts = [0, min(1, spp), min(1 + (spp - 1) // 3, spp), spp]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            ses.render(a, b - a, mrr, **kw)
+    s, s2, c = ses.read()
+    ses.close()
+    assert np.array_equal(c, rc) and _same(s, rs) and _same(s2, rs2)
+    # and as a row band of a taller image (the band's first row is not a multiple of the tile height)
+    if H >= 5:
+        r0, r1 = 2, H - 1
+        bs, bs2, bc, _ = gpu_scene.render_host(W, H, spp, mrr, rows=(r0, r1), want_stats=False, **kw)
+        assert np.array_equal(bc, rc[r0 * W:r1 * W]) and _same(bs, rs[r0 * W:r1 * W]) and _same(bs2, rs2[r0 * W:r1 * W])
+    hooks_lib.pt_test_set_mutation(b"reset", 0.0)
+
+
 def test_empty_and_degenerate_calls(gpu_scene):
     s, s2, c, st = gpu_scene.render_host(16, 16, 0, 8)
     assert st["segments"] == 0 and not s.any() and not c.any()

@@ -63,9 +63,15 @@ def test_every_segment_of_config1_on_the_shipped_instantiation(models_dir, vlib)
 
 
 @pytest.mark.parametrize("mrr", [1, 2, 3])
-def test_short_paths_and_adaptive_sampling(models_dir, vlib, mrr):
-    """-MRR 1: every segment is a last segment (only camera rays that see the light contribute)."""
-    st = _check(vlib, models_dir, "Tor.obj", 640, 360, 24, mrr, error=0.001)
+@pytest.mark.parametrize("tile_width", [1, 2], ids=["8x8", "16x8"])
+def test_short_paths_and_adaptive_sampling(models_dir, vlib, mrr, tile_width):
+    """-MRR 1: every segment is a last segment (only camera rays that see the light contribute).  A frame of this size would
+    run the 8 x 8-tile variant of the statistics-free kernel; both variants are pinned in turn."""
+    vlib.pt_test_set_mutation(b"tile_width", float(tile_width))
+    try:
+        st = _check(vlib, models_dir, "Tor.obj", 640, 360, 24, mrr, error=0.001)
+    finally:
+        vlib.pt_test_set_mutation(b"reset", 0.0)
     assert st["verify_mismatches"] == 0
 
 
