@@ -375,8 +375,11 @@ struct WaveLds {
     uint32_t pairs[kPairQueue];    // (ray, triangle) work items
     uint32_t level_off[kMaxLevels];// sphere offset of each level of the cluster being walked
     uint32_t level_cnt[kMaxLevels];// number of real nodes of each level
-    AccPlanes<R == 1 ? kSlots : 0> acc;   // R = 1: this tile's accumulators (sum rgb, sum2 rgb, count as int bits); R > 1: they stay in memory
-    static constexpr bool kAccInLds = R == 1;
+    // The tile's accumulators (sum rgb, sum2 rgb, count as int bits) live here for the small-scene kernels with one ray per lane;
+    // the two-rays-per-lane kernel and the big-scene kernels leave them in memory (integrate_kernel: "Where the tile's
+    // accumulators live"): the LDS is worth a wave per SIMD to them.
+    static constexpr bool kAccInLds = R == 1 && !kPrefilter;
+    AccPlanes<kAccInLds ? kSlots : 0> acc;
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0, w_partial = 0;   // wave-uniform, live in SGPRs
@@ -1192,11 +1195,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
     // The tile's accumulators live in LDS for the whole launch (read once, written once: exactly the algorithmic
     // 56 B/pixel of HBM traffic).  Keeping them in VGPRs costs a wave per SIMD; read-modify-writing them in HBM at every
     // emitter hit moved 10x the algorithmic bytes, because each hit touches three sparse cache lines.
-    // Where the tile's accumulators live.  One ray per lane: in LDS for the whole work item (read once, written once: exactly
-    // the algorithmic 56 B/pixel of HBM traffic; keeping them in VGPRs costs a wave per SIMD).  Two rays per lane: in memory,
-    // read-modify-written when a path reaches an emitter (1 % of the samples): the 3.5 KB of LDS they would take are what
-    // separates 4 from 5 waves per SIMD there, worth 8 % of the frame time (profiles/r03_ab_logs.txt, ab52), while the extra
-    // traffic -- three sparse cache lines in and out per contribution, ~2 GB per 256-spp frame -- is 0.3 % of the HBM peak.
+    // Where the tile's accumulators live.  Small scenes, one ray per lane: in LDS for the whole work item (read once, written
+    // once: exactly the algorithmic 56 B/pixel of HBM traffic; keeping them in VGPRs costs a wave per SIMD).  Two rays per lane,
+    // and big scenes: in memory, read-modify-written when a path reaches an emitter (1 % of the samples): the LDS they would
+    // take (3.5 KB / 1.8 KB per wave) is what separates 4 from 5 waves per SIMD in the first and 5 from 6 in the second, worth
+    // 8 % and 3 % of the frame time (profiles/r03_ab_logs.txt, ab52 / ab54), while the extra traffic -- three sparse cache lines
+    // in and out per contribution, ~0.4 GB per 256-spp frame -- is 0.08 % of the HBM peak.
     constexpr bool kAccInLds = decltype(lds)::kAccInLds;
     if constexpr (kAccInLds) {
 #pragma unroll

@@ -37,7 +37,7 @@ def usage():
 HOT = {
     "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("small scenes, two pixels per lane (the headline kernel)", 5, 8192),
     "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb1EEEvNS_10RenderArgsE": ("small scenes, one pixel per lane (small launches)", 6, 6826),
-    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 5, 8192),
+    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 6, 6826),
 }
 
 
