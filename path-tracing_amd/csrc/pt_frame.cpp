@@ -308,11 +308,10 @@ int frame_read_impl(pt_frame *f, float *sum, float *sum2, int32_t *count) {
 
 int frame_clear_impl(pt_frame *f) {
     if (!f) return fail(PT_ERR_INVALID_ARGUMENT, "null frame");
-    // the receives of a gather still in flight write into the root planes: they finish first
-    if (f->gather_stream) {
-        PT_HIP_TRY(hipSetDevice(f->devices[0]));
-        PT_HIP_TRY(hipStreamSynchronize(f->gather_stream));
-    }
+    // No wait for a gather still in flight: every band clears only what it renders into, on its own stream -- after its own
+    // sends (same stream) -- and the rows of the root's planes that the receives write belong to other bands; nobody clears
+    // them, the next gather overwrites them.  So a loop of clear / render / gather keeps all devices busy while the previous
+    // frame's bands are still on their way to the root.
     for (pt_session *s : f->sessions) {
         const int rc = pt_session_clear(s);
         if (rc != PT_OK) return rc;
