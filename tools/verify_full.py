@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""Every segment of the full-size frames against the reference's all-triangles loop (libpt_verify.so), beyond what the
-test suite runs:  python tools/verify_full.py   ->  one line per frame (segments checked, mismatches, seconds)."""
+"""Every segment of the full-size frames against the reference's all-triangles loop, beyond what the test suite runs:
+
+    python tools/verify_full.py [shipped]   ->  one line per frame (segments checked, mismatches, seconds)
+
+Without an argument: libpt_verify.so (the statistics instantiations, full search on every segment).  `shipped`:
+libpt_verify_shipped.so -- the statistics-free instantiations a caller without pt_render_stats gets (two pixels per lane,
+emitter-first last segments; big scenes: the can-reach filter), where a filtered last segment may report a miss only if the
+reference's hit has no emissive lobe (tests/test_gpu_verify_shipped.py)."""
 import importlib
 import os
 import sys
@@ -13,7 +19,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import make_replicated_scene as M
 
 pt = importlib.import_module("path-tracing_amd")
-L = pt.load_library(pt.VERIFY_LIB_PATH)
+shipped = len(sys.argv) > 1 and sys.argv[1] == "shipped"
+L = pt.load_library(os.path.join(ROOT, "path-tracing_amd", "lib", "libpt_verify_shipped.so") if shipped else pt.VERIFY_LIB_PATH)
 L.pt_test_set_mutation(b"reset", 0.0)
 models = os.path.join(ROOT, "models") + "/"
 jobs = [("configs[2] Tor.obj 1920x1080x1024spp", models, "Tor.obj", 1920, 1080, 1024),
