@@ -129,3 +129,19 @@ def test_random_scene(tmp_path, seed, n_small, n_large, n_dup, few_emitters):
     # with the envelope test compiled in: integrate_kernel<.., .., false, true>)
     q = g.render_host(W, H, spp, 8, want_stats=False)
     assert np.array_equal(q[2], rc) and np.array_equal(q[0].view(np.uint32), rs.view(np.uint32))
+    # A frame of this size runs that kernel's 8 x 8-tile variant; its 16 x 8 variant (two pixels per lane, 128 rays per
+    # wave-segment, accumulators in memory) is pinned through the test-hook build of the same kernels -- and, in the build that
+    # checks every segment of the statistics-free instantiations against the all-triangles loop, must not show one mismatch.
+    hooks = pt.load_library(pt.TESTHOOKS_LIB_PATH)
+    vship = pt.load_library(os.path.join(os.path.dirname(pt.LIB_PATH), "libpt_verify_shipped.so"))
+    for L in (hooks, vship):
+        L.pt_test_set_mutation(b"reset", 0.0)
+        L.pt_test_set_mutation(b"tile_width", 2.0)
+        try:
+            h = pt.Scene.load_obj(d, "f.obj", device=0, library=L)
+            hs, hs2, hc, hst = h.render_host(W, H, spp, 8, want_stats=(L is vship))
+        finally:
+            L.pt_test_set_mutation(b"reset", 0.0)
+        assert np.array_equal(hc, rc) and np.array_equal(hs.view(np.uint32), rs.view(np.uint32)) and np.array_equal(hs2.view(np.uint32), rs2.view(np.uint32))
+        if L is vship:
+            assert hst["verify_checked"] == rst["segments"] and hst["verify_mismatches"] == 0
