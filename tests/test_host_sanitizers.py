@@ -28,3 +28,21 @@ def test_scene_code_is_clean_under_asan_and_ubsan(tmp_path, models_dir):
     m = re.search(r"n 3000: \d+ clusters \d+ spheres \d+ bary (\d+) bary_all (\d+) slots (\d+) bvh", out)
     assert m and int(m.group(1)) == int(m.group(2)) + 4 and int(m.group(2)) >= 3000 and int(m.group(3)) > 300
     assert out.count("bad obj -> 0") == 4 and "bad obj -> 1" in out        # four rejected with a message, the empty file loads (no triangles)
+
+
+@pytest.mark.skipif(shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"), reason="g++ or the HIP headers are not available")
+def test_c_api_host_side_is_clean_under_tsan(tmp_path, models_dir):
+    """pt_resolve runs bands of rows on several host threads and per-device copies of a scene share one hierarchy cache:
+    the C API's host code (pt_capi.cpp, pt_frame.cpp, pt_scene.cpp; kernel launchers stubbed) under ThreadSanitizer, on the CPU."""
+    exe = str(tmp_path / "capi_tsan")
+    csrc = os.path.join(ROOT, "path-tracing_amd", "csrc")
+    build = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+                            "-I", csrc, "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                            os.path.join(ROOT, "tests", "native", "resolve_tsan_main.cpp"), os.path.join(csrc, "pt_capi.cpp"),
+                            os.path.join(csrc, "pt_frame.cpp"), os.path.join(csrc, "pt_scene.cpp"), "-o", exe,
+                            "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe, models_dir], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
+    assert "resolve ok" in run.stdout and "hierarchy threads bad 0" in run.stdout
