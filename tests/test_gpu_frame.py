@@ -156,3 +156,25 @@ def test_cli_bench_mode_reports_whole_frames(tmp_path, models_dir):
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["cxx_frame"] and j["bands"] == 2 and j["transport"] == "device_copies" and j["steps"] == 3
     assert abs(j["value"] - 640 * 360 * 16 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * j["value"]
+
+
+def test_cli_bands_with_skybox_and_a_big_scene(tmp_path, models_dir):
+    """The per-device copies a frame makes inherit the skybox, and a big scene (box tree, accumulators in memory) comes out the
+    same through bands: pt_render -SKYBOX / a 2 318-triangle replica, one device against three rehearsed bands."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import make_replicated_scene as M
+    import oracle_lib as O
+    rng = np.random.default_rng(3)
+    sky = str(tmp_path / "sky.bmp")
+    O.write_bmp(sky, rng.integers(0, 256, (24, 48, 3)).astype(np.uint8))
+    d = str(tmp_path) + "/"
+    M.generate(os.path.join(ROOT, "models"), d, "x9.obj", 9)
+    for tag, extra in (("sky", ["-MODEL_PATH", models_dir, "-SKYBOX", sky]), ("big", ["-MODEL_PATH", d, "-MODEL_NAME", "x9.obj"])):
+        common = ["--W", 200, "--H", 90, "-RPP", 12, "-MRR", 8, "-UPDATE", 0, "-QUIET", 1, "-SEED", 5] + extra
+        a, b = str(tmp_path / f"{tag}_a.bmp"), str(tmp_path / f"{tag}_b.bmp")
+        _run(common + ["-OUT", a], tmp_path)
+        _run(common + ["-OUT", b, "-GPUS", 3, "-REHEARSE", 1], tmp_path)
+        assert _md5(a) == _md5(b), tag
+        assert np.frombuffer(open(a, "rb").read()[54:], np.uint8).any(), tag      # (not two black images)

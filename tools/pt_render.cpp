@@ -250,10 +250,12 @@ int main(int argc, char **argv) {
         }
         rp.pass_begin = rays_count;
         rp.pass_count = slice_end - rays_count;
-        pt_render_stats st;
         const clk::time_point a = clk::now();
-        if (pt_frame_render(frame, &rp, o.time_limit != 0 ? &st : nullptr) != PT_OK) return die("pt_render");
-        if (o.time_limit != 0) ms_per_pass = 1e3 * secs(a, clk::now()) / rp.pass_count;   // the call waited for the kernels
+        if (pt_frame_render(frame, &rp, nullptr) != PT_OK) return die("pt_render");
+        if (o.time_limit != 0) {   // wait for the slice (without asking for statistics: the statistics-free kernels are the fast ones)
+            if (pt_frame_wait(frame) != PT_OK) return die("pt_render");
+            ms_per_pass = 1e3 * secs(a, clk::now()) / rp.pass_count;
+        }
         for (int p = rays_count; p < slice_end; ++p) {
             if (o.update != 0 && p % o.update == 0) {
                 const clk::time_point b = clk::now();
