@@ -113,6 +113,8 @@ int upload(pt_scene *s, int device) {
     if (!sky.empty()) {
         PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_sky), sky.size() + 64));
         PT_HIP_TRY(hipMemcpy(s->d_sky, sky.data(), sky.size(), hipMemcpyHostToDevice));
+        s->sky_w = s->shared->sky_w;
+        s->sky_h = s->shared->sky_h;
     }
     return PT_OK;
 }
@@ -209,8 +211,8 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.bvh_err = t.bvh_err;
     a.mats = scene->d_mats;
     a.sky = scene->d_sky;
-    a.sky_w = scene->d_sky ? scene->shared->sky_w : 0;
-    a.sky_h = scene->d_sky ? scene->shared->sky_h : 0;
+    a.sky_w = scene->d_sky ? scene->sky_w : 0;
+    a.sky_h = scene->d_sky ? scene->sky_h : 0;
     a.n_clusters = static_cast<int32_t>(t.clusters.size());
     a.n_tri = scene->shared->host.n_tri();
     a.n_slots = static_cast<uint32_t>(t.slot_tri.size());
@@ -562,10 +564,15 @@ static int scene_set_skybox_bmp_impl(pt_scene *scene, const char *path) {
             PT_HIP_TRY(hipMemcpy(scene->d_sky, texels.data(), texels.size(), hipMemcpyHostToDevice));
         }
     }
-    // (per-device copies made from this scene AFTERWARDS inherit the skybox; copies made before keep what they had)
-    scene->shared->sky.swap(texels);
-    scene->shared->sky_w = w;
-    scene->shared->sky_h = h;
+    // (per-device copies made from this scene AFTERWARDS inherit the skybox; copies made before keep what they had, with its size)
+    scene->sky_w = w;
+    scene->sky_h = h;
+    {
+        std::lock_guard<std::mutex> lock(scene->shared->cull_mutex);
+        scene->shared->sky.swap(texels);
+        scene->shared->sky_w = w;
+        scene->shared->sky_h = h;
+    }
     return PT_OK;
 }
 

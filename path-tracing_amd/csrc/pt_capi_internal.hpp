@@ -64,6 +64,7 @@ struct pt_scene {
     pt::MatRec *d_mats = nullptr;
     int cu_count = 256;            // compute units of the scene's device
     uint8_t *d_sky = nullptr;
+    int sky_w = 0, sky_h = 0;      // of the texels THIS copy has on its device (the shared host side may have moved on)
     // ensure_cull + the enqueue of a launch happen under launch_mutex (a concurrent render with another eps must not free
     // the tables in between); nothing waits for the device while holding it.
     std::mutex launch_mutex;

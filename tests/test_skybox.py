@@ -125,3 +125,25 @@ def test_gpu_skybox_bit_exact(tmp_path, models_dir, W, H, spp, sw, sh):
     s, s2, c, st = g.render_host(W, H, spp, 8)
     rs, rs2, rc, rst = O.render(o, W, H, spp, 8)
     assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)) and np.array_equal(c, rc)
+
+
+@pytest.mark.gpu
+def test_gpu_device_copies_keep_the_skybox_they_were_made_with(tmp_path, models_dir):
+    """pt_scene_clone_to_device shares the host side of a scene; a copy inherits the skybox set before it was made and keeps
+    it -- texels AND size -- when the original gets another one afterwards."""
+    d = str(tmp_path) + "/"
+    _open_scene(d, models_dir)
+    _write_sky(d + "a.bmp", 64, 32, seed=1)
+    _write_sky(d + "b.bmp", 5, 3, seed=2)
+    g = pt.Scene.load_obj(d, "open.obj", device=0)
+    g.set_skybox(d + "a.bmp")
+    copy = g.clone_to_device(0)               # inherits a.bmp
+    g.set_skybox(d + "b.bmp")                 # the original moves on to a smaller image
+    late = g.clone_to_device(0)               # inherits b.bmp
+    o = O.Scene.load(d, "open.obj")
+    for scene, sky in ((copy, "a.bmp"), (g, "b.bmp"), (late, "b.bmp")):
+        o.set_skybox(d + sky)
+        s, s2, c, st = scene.render_host(40, 24, 6, 8)
+        rs, rs2, rc, rst = O.render(o, 40, 24, 6, 8)
+        assert st["misses"] == rst["misses"] > 0 and np.array_equal(c, rc), sky
+        assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)) and np.array_equal(s2.view(np.uint32), rs2.view(np.uint32)), sky
