@@ -36,6 +36,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
                 with its traced-sample count, and configs[4] (the x64 / x195 replicated scenes) with its own counters
 """
 import argparse
+import datetime
 import csv
 import glob
 import hashlib
@@ -82,9 +83,9 @@ def host_cores():
 
 
 def instantiation(kernel_name):
-    """integrate_kernel<SKY, BIG, STATS, ENV, NARROW> -> (sky, big, stats, env, narrow) as booleans, or None."""
-    m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)(?:,(\w+))?>", kernel_name.replace(" ", ""))
-    return tuple(x == "true" for x in m.groups()) if m else None      # (narrow is False when the name has four arguments)
+    """integrate_kernel<SKY, BIG, STATS, ENV, NARROW, ADAPT> -> (sky, big, stats, env, narrow, adapt) as booleans, or None."""
+    m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)(?:,(\w+))?(?:,(\w+))?>", kernel_name.replace(" ", ""))
+    return tuple(x == "true" for x in m.groups()) if m else None      # (missing trailing arguments read as False)
 
 
 def kernel_source_sha():
@@ -293,7 +294,7 @@ def cpu_baseline(models, target_seconds, pt, scene):
     d = g_rgb.astype(np.float64) - c_rgb.astype(np.float64)
     g_bgr, c_bgr = pt.quantize(g_rgb, gc), pt.quantize(c_rgb, cpu_acc[2])
     accuracy = {"vs": "cpu_baseline sample (same rows, passes, seed; counter RNG on both sides)",
-                "gpu_instantiation": "integrate_kernel<false,false,false,false,false> (statistics-free, two pixels per lane: the one the timed launches run)",
+                "gpu_instantiation": "integrate_kernel<false,false,false,false,false,false> (statistics-free, two pixels per lane: the one the timed launches run)",
                 "rmse_rgb_float_image": [float(np.sqrt(np.mean(d[..., k] ** 2))) for k in range(3)],
                 "max_abs_diff_float_image": float(np.abs(d).max()),
                 "bmp_bytes_differing": int(np.count_nonzero(g_bgr != c_bgr)),
@@ -542,7 +543,7 @@ def main():
             if inst == 64:
                 v = valu_view(pmc_big, r["kernel_ms"], float(st["segments"]))
                 rf = {"bound": "valu_issue", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s", **v,
-                      "kernel": "pt::integrate_kernel<false,true,false,false,false>", "kernel_ms": r["kernel_ms"],
+                      "kernel": "pt::integrate_kernel<false,true,false,false,false,false>", "kernel_ms": r["kernel_ms"],
                       "issue": issue_view(pmc_big, r["kernel_ms"], wseg), "counters_source": pmc_big_source,
                       "l1_hit_rate": (1 - pmc_big["TCP_TCC_READ_REQ_sum"] / pmc_big["TCP_TOTAL_CACHE_ACCESSES_sum"])
                       if pmc_big and pmc_big.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
@@ -566,7 +567,7 @@ def main():
                     cxx["configs3_strong"] = cxx_frame_leg(world, C3_W, C3_H, C3_SPP, max(1, min(args.steps, 5)), 1, args.rehearse_on_one_gpu)
                 store.set("cxx_frame_done", "1")
             else:
-                store.wait(["cxx_frame_done"])
+                store.wait(["cxx_frame_done"], datetime.timedelta(seconds=900))   # two children of at most 300 s each
         else:
             cxx = {"weak": cxx_frame_leg(1, W, H, args.spp, max(1, min(args.steps, 10)), 1, False)}
 
@@ -590,7 +591,7 @@ def main():
             # strided accumulator loads, calibrated 0.76-1.0 : 1 on their known byte count
             traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         if args.save_pmc and pmc and pmc_source.startswith("rocprofv3"):
-            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false,false>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
+            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false,false,false>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
                        "kernel_source_sha": kernel_source_sha(), "kernel_ms": kms, "counters_per_launch": pmc,
                        "collected_by": "bench.py --save-pmc: " + pmc_source,
                        "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes; SQ_INSTS_VALU counts wave-instructions"},
@@ -615,7 +616,7 @@ def main():
             "roofline": {"bound": "valu_issue", "achieved": v["achieved"], "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": v["frac"],
                          "traffic": traffic,
-                         "kernel": "pt::integrate_kernel<false,false,false,false,false>", "kernel_ms": kms,
+                         "kernel": "pt::integrate_kernel<false,false,false,false,false,false>", "kernel_ms": kms,
                          "what": "achieved = executed VALU lane-operations (SQ_INSTS_VALU x 64) / live HIP-event kernel time; "
                                  "peak = 1024 SIMDs x 32 lanes x 2.4 GHz (no FMA: parity forbids contraction); frac counts issued "
                                  "instructions whatever their lane mask, frac_active_lanes = frac x active-lane fraction, useful_fraction = "

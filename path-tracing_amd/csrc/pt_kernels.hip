@@ -353,13 +353,14 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // of the instructions went.  Big scenes keep R = 1 (their rounds are full anyway, their registers are not).
 template <int N> struct AccPlanes { float v[7][N]; };
 template <> struct AccPlanes<0> {};
-template <class Q, int R>
+template <int N> struct FlagWords { uint32_t v[N]; };
+template <> struct FlagWords<0> {};
+template <class Q, int R, bool FLAGS = false>
 struct WaveLds {
     static constexpr int kRays = R, kSlots = 64 * R;
     static constexpr int kNodeStack = Q::kNodeStack, kPairQueue = Q::kPairQueue;
     static constexpr bool kPrefilter = Q::kFiltered > 1;   // big scenes: thin the pairs with the barycentric test first
     static_assert(R == 1 || R == 2, "ray ids take 6 or 7 bits of a work item");
-    static_assert(R == 1 || !kPrefilter, "the box-tree walk and its pre-filter are written for one ray per lane");
     // work-item layouts: sphere-tree stack entries = ray << kNodeSrcShift | level << kNodeLevShift | node index within its level;
     // pairs = slot | ray << 24 (| kUnfiltered << 24 with the pre-filter)
     static constexpr uint32_t kSrcMask = kSlots - 1, kNodeSrcShift = R == 1 ? 26 : 25, kNodeLevShift = kNodeSrcShift - 3;
@@ -380,6 +381,9 @@ struct WaveLds {
     // accumulators live"): the LDS is worth a wave per SIMD to them.
     static constexpr bool kAccInLds = R == 1 && !kPrefilter;
     AccPlanes<kAccInLds ? kSlots : 0> acc;
+    // adaptive-sampling instantiation of the two-pixel kernel: the cached "variance is low" answer of the tile's pixels, by pixel
+    // (lane + 64 k): another lane may be the one that traces a lane's second pixel, see "Compaction" in integrate_kernel
+    FlagWords<FLAGS ? kSlots : 0> low;
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0, w_partial = 0;   // wave-uniform, live in SGPRs
@@ -420,7 +424,7 @@ struct NoStats {
 #define PT_STAMP(st, idx) do { } while (0)
 #endif
 
-constexpr uint32_t kUnfiltered = 64u;   // added to the lane number of a pair: the pre-filter must not judge it
+constexpr uint32_t kUnfiltered = 128u;  // added to the ray id of a pair (bit 31 of the work item): the pre-filter must not judge it
 
 // float -> uint32 whose unsigned order is the float order (for ds_min_u64 keys)
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
@@ -506,12 +510,23 @@ __device__ __forceinline__ unsigned long long brute_force_key(const RenderArgs &
 // emis_flag (wave-uniform, honoured only by instantiations with EMIS): search only where emitters are (RenderArgs::emis_*) --
 // the closest hit among a SUPERSET of the emitters, which is all the caller needs to know whether the ray's closest hit can be
 // one (see the last segment in the kernel).
-template <bool ENV, bool EMIS, class Lds, class Stats>
+// DYN (the adaptive-sampling instantiation of the two-rays-per-lane kernel): `two` (wave-uniform) says whether any lane's second
+// ray slot is in use this pass; when it is not, everything per-ray about slot 1 is skipped by scalar branches and the segment
+// costs about what a one-ray-per-lane segment costs (PT_SLOT_ON).  Without DYN the guards fold away.
+#define PT_SLOT_ON(k) ((k) == 0 || k1_on)
+#ifdef PT_GUARD_MINOR_OFF
+#define PT_SLOT_ON2(k) true
+#else
+#define PT_SLOT_ON2(k) PT_SLOT_ON(k)
+#endif
+template <bool ENV, bool EMIS, bool DYN = false, class Lds, class Stats>
 __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray (&q)[Lds::kRays], const bool (&live)[Lds::kRays],
                                             const bool (&in_envelope)[Lds::kRays], int lane, float eps, float (&best)[Lds::kRays],
-                                            int (&hit)[Lds::kRays], const ExactRec *(&hit_rec)[Lds::kRays], Stats &st, bool emis_flag = false) {
+                                            int (&hit)[Lds::kRays], const ExactRec *(&hit_rec)[Lds::kRays], Stats &st, bool emis_flag = false,
+                                            bool two = true) {
     constexpr int R = Lds::kRays;   // rays per lane: ray k of lane l has the id l + 64 k
     const bool emis_only = EMIS && emis_flag;
+    const bool k1_on = !DYN || two;   // (slot 1 of a lane is never live when `two` is false: the guards only save its instructions)
     // `valid` below = rays that go through the culling hierarchy; live rays outside the envelope its margins were derived
     // for get every slot as a candidate instead (rare: see the caller).
     bool valid[R];
@@ -533,6 +548,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
 #pragma unroll
     for (int k = 0; k < R; ++k) {
+        if (!PT_SLOT_ON2(k)) continue;
         const int id = lane + 64 * k;
         lds.best[id] = ~0ull;
         lds.ray[0][id] = q[k].ox; lds.ray[1][id] = q[k].oy; lds.ray[2][id] = q[k].oz;
@@ -574,7 +590,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 // test, and the survivors are re-packed so that exact rounds stay full.
                 bool keep = false;
                 if (active) {
-                    const uint32_t src = (e >> 24) & 63u, tri = e & 0xFFFFFFu;
+                    const uint32_t src = (e >> 24) & Lds::kSrcMask, tri = e & 0xFFFFFFu;
                     Ray r;
                     r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                     r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
@@ -584,7 +600,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     rec.n[0] = c0.x; rec.n[1] = c0.y; rec.n[2] = c0.z; rec.w = c0.w;
                     rec.au[0] = c1.x; rec.au[1] = c1.y; rec.au[2] = c1.z; rec.cu = c1.w;
                     rec.av[0] = c2.x; rec.av[1] = c2.y; rec.av[2] = c2.z; rec.cv = c2.w;
-                    keep = !cull_reject(rec, r, a.k1, a.k2, a.a_max_all, a.m0_all, a.t_guard_all) || (e >> 30) != 0u;   // bit 30: never filtered
+                    keep = !cull_reject(rec, r, a.k1, a.k2, a.a_max_all, a.m0_all, a.t_guard_all) || (e >> 31) != 0u;   // bit 31: never filtered
 #ifdef PT_DBG_NO_PREFILTER
                     keep = true;
 #endif
@@ -610,6 +626,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         uint32_t pos = n_pairs + excl;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
+            if (!PT_SLOT_ON2(k)) continue;
             emit_bits(lds.pairs, pos, bits[k], tri0 | ((static_cast<uint32_t>(lane + 64 * k) | flag) << 24));
             pos += __builtin_popcount(bits[k]);
         }
@@ -626,7 +643,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     auto push_pairs_any = [&](const uint32_t (&bits)[R], uint32_t tri0, uint32_t flag) {
         uint32_t cnt = 0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) cnt += __builtin_popcount(bits[k]);
+        for (int k = 0; k < R; ++k)
+            if (PT_SLOT_ON2(k)) cnt += __builtin_popcount(bits[k]);
         const uint32_t incl = wave_scan_inclusive(cnt), total = wave_last(incl);
         if (total == 0) return;
         if (n_pairs + total > kPairQueue) drain_pairs(0);
@@ -640,7 +658,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             bool some = false;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                part[k] = bits[k] & (((1u << kSlice) - 1u) << lo);
+                part[k] = PT_SLOT_ON2(k) ? bits[k] & (((1u << kSlice) - 1u) << lo) : 0u;
                 pc2 += __builtin_popcount(part[k]);
                 some = some || part[k] != 0;
             }
@@ -667,11 +685,12 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     auto add_pending = [&](const uint32_t (&bits)[R], uint32_t tri0, uint32_t width) {   // tri0, width wave-uniform
         if (pend_open && tri0 >= pend_tri0 && tri0 + width <= pend_tri0 + 32u) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) pend[k] |= bits[k] << (tri0 - pend_tri0);
+            for (int k = 0; k < R; ++k)
+                if (PT_SLOT_ON2(k)) pend[k] |= bits[k] << (tri0 - pend_tri0);
         } else {
             flush_pending();
 #pragma unroll
-            for (int k = 0; k < R; ++k) pend[k] = bits[k];
+            for (int k = 0; k < R; ++k) pend[k] = PT_SLOT_ON2(k) ? bits[k] : 0u;
             pend_tri0 = tri0;
             pend_open = true;
         }
@@ -711,7 +730,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         if (!kSphereTrees && kind == 0) continue;
         bool pc[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) pc[k] = (kSphereTrees && kind == 0) ? valid[k] & sphere_keep(cp[0], cp[1], cp[2], cp[3], q[k]) : valid[k];
+        for (int k = 0; k < R; ++k) {
+            pc[k] = false;
+            if (PT_SLOT_ON(k)) pc[k] = (kSphereTrees && kind == 0) ? valid[k] & sphere_keep(cp[0], cp[1], cp[2], cp[3], q[k]) : valid[k];
+        }
         if (!any_ray(pc)) continue;
         if (kSphereTrees && kind == 0) {
             // ---- small triangles: an 8-ary tree of bounding spheres, walked with a wave-wide LIFO of (ray, node) items
@@ -736,6 +758,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             auto push_top = [&](uint32_t top) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
+                    if (!PT_SLOT_ON2(k)) continue;
                     while (__any(tmask[k] != 0)) {   // at most 8 x 64 R items > capacity: drained in the expansion loop before overflow
                         const bool has = tmask[k] != 0;
                         const unsigned long long ball = __ballot(has);
@@ -758,6 +781,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 uint32_t rcnt = 0;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
+                    pcb[k] = 0;
+                    if (!PT_SLOT_ON2(k)) continue;
                     pcb[k] = __ballot(pc[k]);
                     rcnt += __builtin_popcountll(pcb[k]);
                 }
@@ -771,6 +796,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                         uint32_t at = 0;   // the stack is empty here: the compacted ray ids go to its bottom
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
+                            if (!PT_SLOT_ON2(k)) continue;
                             if (pc[k]) lds.nodes[at + lanes_below(pcb[k])] = static_cast<uint32_t>(lane + 64 * k);
                             at += __builtin_popcountll(pcb[k]);
                         }
@@ -832,7 +858,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             for (uint32_t j = 0; j < top_cnt; ++j) {
                 const float sx = tp[4 * j], sy = tp[4 * j + 1], sz = tp[4 * j + 2], sr = tp[4 * j + 3];
 #pragma unroll
-                for (int k = 0; k < R; ++k) tmask[k] |= sphere_keep(sx, sy, sz, sr, q[k]) ? (1u << j) : 0u;
+                for (int k = 0; k < R; ++k)
+                    if (PT_SLOT_ON(k)) tmask[k] |= sphere_keep(sx, sy, sz, sr, q[k]) ? (1u << j) : 0u;
             }
 #pragma unroll
             for (int k = 0; k < R; ++k) tmask[k] = pc[k] ? tmask[k] : 0u;
@@ -949,12 +976,14 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 auto quad = [&](uint32_t k0) {
                     const CullRec rec = load_cull(bp + 12 * k0);
 #pragma unroll
-                    for (int k = 0; k < R; ++k) m[k] |= (~cull_reject_quad(rec, q[k], k1, k2, a_max, m0q, t_guard) & 3u) << k0;
+                    for (int k = 0; k < R; ++k)
+                        if (PT_SLOT_ON(k)) m[k] |= (~cull_reject_quad(rec, q[k], k1, k2, a_max, m0q, t_guard) & 3u) << k0;
                 };
                 auto single = [&](uint32_t slot) {
                     const CullRec rec = load_cull(bp + 12 * slot);
 #pragma unroll
-                    for (int k = 0; k < R; ++k) m[k] |= cull_reject(rec, q[k], k1, k2, a_max, m0, t_guard) ? 0u : (1u << slot);
+                    for (int k = 0; k < R; ++k)
+                        if (PT_SLOT_ON(k)) m[k] |= cull_reject(rec, q[k], k1, k2, a_max, m0, t_guard) ? 0u : (1u << slot);
                 };
                 if (emis_only && n_words == 1) {   // only the records that hold an emitter (the light of a room: one quad)
                     for (uint32_t rest = (a.emis_large_w0 | (a.emis_large_w0 >> 1)) & pair_bits; rest != 0; rest &= rest - 1) {
@@ -1030,9 +1059,13 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             }
             uint32_t n_nodes;
             {
-                const unsigned long long vb = __ballot(valid[0]);
-                if (valid[0]) lds.nodes[lanes_below(vb)] = static_cast<uint32_t>(lane) << 26;   // the root, for every live ray
-                n_nodes = __builtin_popcountll(vb);
+                n_nodes = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {   // the root, for every live ray
+                    const unsigned long long vb = __ballot(valid[k]);
+                    if (valid[k]) lds.nodes[n_nodes + lanes_below(vb)] = static_cast<uint32_t>(lane + 64 * k) << Lds::kNodeSrcShift;
+                    n_nodes += __builtin_popcountll(vb);
+                }
                 wave_sync();
             }
             while (n_nodes > 0) {
@@ -1042,8 +1075,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 bool leaf = false;
                 if (static_cast<uint32_t>(lane) < cnt) {
                     const uint32_t e = lds.nodes[n_nodes - 1 - lane];
-                    src = e >> 26;
-                    const uint32_t node = e & 0x3FFFFFFu;
+                    src = e >> Lds::kNodeSrcShift;
+                    const uint32_t node = e & ((1u << Lds::kNodeSrcShift) - 1u);
                     Ray r;
                     r.ox = lds.ray[0][src]; r.oy = lds.ray[1][src]; r.oz = lds.ray[2][src];
                     r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
@@ -1093,7 +1126,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 {
                     const uint32_t excl = incl - packed;
                     emit_bits(leaf ? lds.pairs : lds.nodes, leaf ? n_pairs + (excl >> 16) : n_nodes + (excl & 0xFFFFu), m8,
-                              leaf ? (base | (src << 24)) : ((src << 26) | base));
+                              leaf ? (base | (src << 24)) : ((src << Lds::kNodeSrcShift) | base));
                     n_nodes += tot & 0xFFFFu;
                     n_pairs += tot >> 16;
                 }
@@ -1118,6 +1151,12 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     PT_STAMP(st, 5);   // exact rounds
 #pragma unroll
     for (int k = 0; k < R; ++k) {
+        if (!PT_SLOT_ON2(k)) {   // (nobody's ray)
+            hit[k] = -1;
+            hit_rec[k] = a.exact;
+            best[k] = __builtin_inff();
+            continue;
+        }
         const unsigned long long key = lds.best[lane + 64 * k];
         const uint32_t key_lo = static_cast<uint32_t>(key);
         hit[k] = (key == ~0ull) ? -1 : static_cast<int>(kPackSlot ? key_lo >> 16 : key_lo);
@@ -1157,18 +1196,23 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 #ifndef PT_RAYS_PER_LANE
 #define PT_RAYS_PER_LANE 2   // pixels (rays) per lane of the small-scene, statistics-free, skybox-free kernel; 1 = one 8 x 8 tile per wave
 #endif
+#ifndef PT_BIG_RAYS_PER_LANE
+#define PT_BIG_RAYS_PER_LANE 1   // the same for the statistics-free, skybox-free big-scene kernel
+#endif
 // rays per lane of an instantiation: the launch geometry (tile width) follows from it on the host as well
 template <bool SKY, bool BIG, bool STATS>
-constexpr int rays_per_lane() { return (!SKY && !BIG && !STATS) ? PT_RAYS_PER_LANE : 1; }
+constexpr int rays_per_lane() { return (!SKY && !STATS) ? (BIG ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1; }
 
 // NARROW = the statistics-free small-scene kernel with ONE pixel per lane (8 x 8 tiles): for launches with too few pixels to
 // fill the chip with 16 x 8 tiles (small previews, thin row bands) -- half as many waves would leave wave slots empty.
-template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW = false>
+// ADAPT = the two-pixel kernel for launches with adaptive sampling on (error >= 0): see "Compaction" in the pass loop.
+template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW = false, bool ADAPT = false>
 __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!NARROW && rays_per_lane<SKY, BIG, STATS>() > 1)) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
-    static_assert(!NARROW || (!SKY && !BIG && !STATS), "only the statistics-free small-scene kernel has a narrow variant");
+    static_assert(!NARROW || (!SKY && !STATS), "only the statistics-free, skybox-free kernels have a narrow variant");
     constexpr int R = NARROW ? 1 : rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
+    static_assert(!ADAPT || (R == 2 && !BIG), "compaction moves a lane's second pixel into another lane's free first slot");
     constexpr int kTW = kTileW * R;
-    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R> lds;   // one wave per workgroup: all wave-private
+    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R, ADAPT> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
     // Work item = (pixel tile, chunk of passes), claimed from a ticket counter in chunk-major order: all tiles' first
@@ -1264,14 +1308,30 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
                                                       lds.acc.v[5][id], __float_as_int(lds.acc.v[6][id]));
         }
     }
+    // ADAPT: the pixel the lane's FIRST ray slot works on in the current pass -- owner lane | column block << 6: its own first
+    // pixel (= lane), or, in a compacted pass, another lane's second pixel (see "Compaction" in the pass loop).
+    uint32_t job0 = static_cast<uint32_t>(lane);
+    if constexpr (ADAPT) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) lds.low.v[lane + 64 * k] = lowvar[k] ? 1u : 0u;
+        wave_sync();
+    }
     // adds one contribution (material.h:74-77) to pixel k of the lane and refreshes its cached adaptive-sampling answer
     auto contribute = [&](int k, float cr, float cg, float cb) {
         float n0, n1, n2, p0, p1, p2;
         int nn;
         if constexpr (!kAccInLds) {
             // (the pixel's index is rebuilt from the lane number and the tile's wave-uniform corner, like the camera ray's x, y)
-            const uint32_t le = opaque(static_cast<uint32_t>(lane));
-            const size_t p = static_cast<size_t>(tile_y0 + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * k);
+            uint32_t le = opaque(static_cast<uint32_t>(lane));
+            int kb = k;
+            if constexpr (ADAPT) {
+                if (k == 0) {   // (opaque: or the addresses are formed at the head of the pass and held -- spilled -- until here)
+                    const uint32_t j = opaque(job0);
+                    le = j & 63u;
+                    kb = static_cast<int>(j >> 6);
+                }
+            }
+            const size_t p = static_cast<size_t>(tile_y0 + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * kb);
             n0 = a.sum[3 * p] + cr; n1 = a.sum[3 * p + 1] + cg; n2 = a.sum[3 * p + 2] + cb;
             p0 = a.sum2[3 * p] + cr * cr; p1 = a.sum2[3 * p + 1] + cg * cg; p2 = a.sum2[3 * p + 2] + cb * cb;
             nn = a.count[p] + 1;
@@ -1287,7 +1347,13 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
             lds.acc.v[3][id] = p0; lds.acc.v[4][id] = p1; lds.acc.v[5][id] = p2;
             lds.acc.v[6][id] = __int_as_float(nn);
         }
-        lowvar[k] = low_variance(n0, n1, n2, p0, p1, p2, nn);
+        const bool now_low = low_variance(n0, n1, n2, p0, p1, p2, nn);
+        if constexpr (ADAPT) {
+            // (the answers live in LDS, by pixel, whoever traces it; the owners read them at the head of every pass)
+            lds.low.v[k == 0 ? opaque(job0) : static_cast<uint32_t>(lane) + 64u] = now_low ? 1u : 0u;
+        } else {
+            lowvar[k] = now_low;
+        }
     };
     // statistics are wave-level (uniform) counts: they live in SGPRs
     using Count = std::conditional_t<STATS, uint32_t, Ignored>;
@@ -1301,6 +1367,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
     const float eps = a.eps;
 #ifdef PT_VERIFY_SHIPPED
     uint32_t v_checked = 0, v_bad = 0;   // wave-uniform
+    uint32_t v_compacted = 0;            // passes a wave ran compacted (ADAPT): reported where this build has no other use for a field
 #endif
     auto any_of = [&](const bool (&b)[R]) {   // wave-uniform: any ray of the wave
         bool v = b[0];
@@ -1312,12 +1379,59 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
     for (int pass = pass_first; pass < pass_last; ++pass) {
         // Adaptive skip, main.cpp:118-125.
         bool skip[R], traced[R];
+        if constexpr (ADAPT) {
+            wave_sync();   // (the flags written while shading the last pass, possibly by other lanes)
+#pragma unroll
+            for (int k = 0; k < R; ++k) lowvar[k] = lds.low.v[lane + 64 * k] != 0u;
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             skip[k] = !in_image[k] || (pass > 10 && (pass % 4) && lowvar[k]);
             traced[k] = !skip[k];
         }
         if (!any_of(traced)) continue;
+        // Compaction (ADAPT).  With adaptive sampling on, most pixels of a tile sit out most passes of the second half of a
+        // frame (Tor.obj, -ERR 0.001, 256 spp: 46 of a tile's 128 pixels are still traced at the end), scattered over the tile:
+        // a wave with two pixels per lane would run nearly every pass at full cost for a third of the rays.  So a pass in which
+        // at most 64 of the tile's pixels are traced moves every traced SECOND pixel into the free first slot of some other
+        // lane (ranks by ballot, the lane numbers through LDS) and runs with the second slots switched off (`two`): about the
+        // cost of a one-pixel-per-lane pass.  A pixel's samples do not depend on the lane that traces them (the counter RNG is
+        // keyed by the pixel, the search returns the minimum over the same candidates), so the frame does not change.
+        bool two = true;   // wave-uniform: some lane's second ray slot is in use this pass
+        // the RNG's pixel index of ray slot k (ADAPT: slot 0's is rebuilt from job0 where it is used, not kept in a register)
+        auto rng_pixel = [&](int k) {
+            if constexpr (ADAPT) {
+                if (k == 0) {
+                    const uint32_t jl = opaque(job0) & 63u;
+                    return static_cast<uint32_t>(static_cast<size_t>(tile_y0 + static_cast<int>(jl / kTileW)) * a.width +
+                                                 (tile_x0 + static_cast<int>(jl % kTileW) + kTileW * static_cast<int>(opaque(job0) >> 6)));
+                }
+            }
+            return opaque(gpix[k]);
+        };
+        if constexpr (ADAPT) {
+            job0 = static_cast<uint32_t>(lane);
+            const unsigned long long b0 = __ballot(traced[0]), b1 = __ballot(traced[1]);
+            const uint32_t n0 = __builtin_popcountll(b0), n1 = __builtin_popcountll(b1);
+            if (n1 == 0) {
+                two = false;
+            } else if (n0 + n1 <= 64u) {
+                two = false;
+                if (traced[1]) lds.pairs[lanes_below(b1)] = static_cast<uint32_t>(lane);   // (the queues are empty between two searches)
+                wave_sync();
+                const uint32_t free_rank = lanes_below(~b0);
+                if (!traced[0] && free_rank < n1) {
+                    job0 = lds.pairs[free_rank] | 64u;
+                    skip[0] = false;
+                }
+                skip[1] = true;
+                wave_sync();
+#ifdef PT_VERIFY_SHIPPED
+                ++v_compacted;
+#endif
+            }
+        }
+        const bool k1_on = two;   // (PT_SLOT_ON)
 
         // Primary ray, main.cpp:126-129 + Ray ctor ray.h:21-25 (double arithmetic, then narrowed).
         Ray q[R];
@@ -1327,9 +1441,9 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
         for (int k = 0; k < R; ++k) {
             tr[k] = tg[k] = tb[k] = 1.0f;
             depth[k] = mrr;
-            if (!skip[k]) {
+            if (PT_SLOT_ON(k) && !skip[k]) {
                 uint32_t w0, w1, w2, w3;
-                philox4x32_10(opaque(gpix[k]), static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
+                philox4x32_10(rng_pixel(k), static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
                 const double jx = jitter_double(w0), jy = jitter_double(w1);
                 // x, y are made opaque once per pass so that their int->double conversions (and the doubles of width and
                 // height) are redone here instead of being hoisted out of the pass loop, where they would occupy eight
@@ -1341,6 +1455,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
                 if constexpr (!BIG) {
                     xi = tile_x0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) % kTileW) + kTileW * k;
                     yi = tile_y0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) / kTileW);
+                }
+                if constexpr (ADAPT) {
+                    if (k == 0) {
+                        xi = tile_x0 + static_cast<int>((job0 & 63u) % kTileW) + kTileW * static_cast<int>(job0 >> 6);
+                        yi = tile_y0 + static_cast<int>((job0 & 63u) / kTileW);
+                    }
                 }
                 int wi = a.width, hi = a.height;
                 asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
@@ -1433,7 +1553,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
             }
             for (;;) {
                 if (BIG && !any_of(searched)) break;
-                closest_hit<ENV, kLastSegmentFilter>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase);
+                closest_hit<ENV, kLastSegmentFilter, ADAPT>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase, two);
                 if (!emis_phase) break;
                 emis_phase = false;
 #pragma unroll
@@ -1480,7 +1600,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
             for (int k = 0; k < R; ++k) {
             if constexpr (STATS) n_miss += __builtin_popcountll(__ballot(valid[k] && hit[k] < 0));
             bool contributed = false;
-            if (valid[k]) {
+            if (PT_SLOT_ON(k) && valid[k]) {
                 if (hit[k] < 0) {
                     if (SKY) {   // skybox miss shader, scene.cpp:126-154 (note: the path throughput is NOT applied)
                         const float pi = 3.141593f;
@@ -1522,7 +1642,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
                     // another one (see below: nothing else of that segment survives it).
                     uint32_t w0 = 0, w1 = 0, w2 = 0, w3;
                     if (depth[k] + 1 < mrr || (m2v.x >= 2 && (m2v.y == 0 || m2v.z == 0)))
-                        philox4x32_10(opaque(gpix[k]), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth[k]), 0u, a.seed, kPhiloxKey1,
+                        philox4x32_10(rng_pixel(k), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth[k]), 0u, a.seed, kPhiloxKey1,
                                       w0, w1, w2, w3);
                     int kind;
                     if (m2v.x == 0) {
@@ -1652,6 +1772,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
     if (a.stats && lane == 0) {
         atomicAdd(&a.stats[9], static_cast<unsigned long long>(v_checked));
         if (v_bad) atomicAdd(&a.stats[10], static_cast<unsigned long long>(v_bad));
+        if (v_compacted) atomicAdd(&a.stats[8], static_cast<unsigned long long>(v_compacted));   // (pt_render_stats::partial_commit_rounds)
     }
 #endif
     if constexpr (STATS) if (a.stats && lane == 0) {
@@ -1755,7 +1876,7 @@ hipError_t launch_integrator(const RenderArgs &args0, hipStream_t stream) {
     RenderArgs args = args0;
     args.blockprof = d_cnt;
     char name[128];
-    std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dELb0EEEvNS_10RenderArgsE", args.sky ? 1 : 0,
+    std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dELb0ELb0EEEvNS_10RenderArgsE", args.sky ? 1 : 0,
                   args.n_tri > kBigSceneTriangles ? 1 : 0, args.stats ? 1 : 0, args.may_leave_envelope ? 1 : 0);
     hipFunction_t f;
     e = hipModuleGetFunction(&f, mod, name);
@@ -1782,7 +1903,7 @@ hipError_t integrator_waves_per_cu(const RenderArgs &, int *waves) {
     return hipSuccess;
 }
 void integrator_plan_tiles(RenderArgs &args, int, int) {   // (the instrumented code object holds the wide variant only)
-    const int rays = (!args.sky && args.n_tri <= kBigSceneTriangles && !args.stats) ? PT_RAYS_PER_LANE : 1;
+    const int rays = (!args.sky && !args.stats) ? (args.n_tri > kBigSceneTriangles ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
     args.narrow = 0;
     args.blocks_x = (args.width + kTileW * rays - 1) / (kTileW * rays);
     args.n_tiles = static_cast<uint32_t>(args.blocks_x) * static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
@@ -1808,11 +1929,19 @@ void with_instantiation(const RenderArgs &args, F &&f) {
     const bool stats = launch_with_stats(args);
     auto pick = [&](auto sky, auto bg, auto st) {
         constexpr bool S = decltype(sky)::value, B = decltype(bg)::value, T = decltype(st)::value;
-        if constexpr (!S && !B && !T) {
+        if constexpr (!S && !T && rays_per_lane<S, B, T>() > 1) {
             if (args.narrow) {
-                if (args.may_leave_envelope) f(integrate_kernel<false, false, false, true, true>, 17);
-                else f(integrate_kernel<false, false, false, false, true>, 16);
+                if (args.may_leave_envelope) f(integrate_kernel<false, B, false, true, true>, 17 + 2 * B);
+                else f(integrate_kernel<false, B, false, false, true>, 16 + 2 * B);
                 return;
+            }
+            if constexpr (!B) {
+                // adaptive sampling on: the instantiation that compacts sparse passes (not built with the rare envelope test:
+                // one more spilled register there)
+                if (args.error >= 0.0f && !args.may_leave_envelope) {
+                    f(integrate_kernel<false, false, false, false, false, true>, 20);
+                    return;
+                }
             }
         }
         if (args.may_leave_envelope) f(integrate_kernel<S, B, T, true>, ((S * 2 + B) * 2 + T) * 2 + 1);
@@ -1848,7 +1977,7 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
 void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
     const bool sky = args.sky != nullptr, big = args.n_tri > kBigSceneTriangles, stats = launch_with_stats(args);
     const uint32_t rows = static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
-    int rays = (!sky && !big && !stats) ? PT_RAYS_PER_LANE : 1;
+    int rays = (!sky && !stats) ? (big ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
     args.narrow = 0;
     if (rays > 1) {
         const uint32_t wide_tiles = static_cast<uint32_t>((args.width + kTileW * rays - 1) / (kTileW * rays)) * rows;
@@ -1869,7 +1998,7 @@ void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
 // calculation (registers, LDS, launch bounds): the scheduler's count of wave slots.  Asked once per instantiation and device.
 hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves) {
     constexpr int kDevices = 16;
-    static std::atomic<int> cache[kDevices][18];   // 0 = not asked yet
+    static std::atomic<int> cache[kDevices][21];   // 0 = not asked yet
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -72,7 +72,7 @@ def test_bench_emits_one_valid_json_line():
     assert rep["x64"]["triangles"] == 16398 and rep["x195"]["triangles"] == 49934
     assert rep["x64"]["value"] > rep["x195"]["value"] > 100.0
     rb = rep["x64"]["roofline"]
-    assert rb["kernel"] == "pt::integrate_kernel<false,true,false,false,false>" and rb["achieved"] is not None, rb["counters_source"]
+    assert rb["kernel"] == "pt::integrate_kernel<false,true,false,false,false,false>" and rb["achieved"] is not None, rb["counters_source"]
     assert 0 < rb["useful_fraction"] < rb["frac_active_lanes"] < rb["frac"] <= 1.0
     assert 0.3 < rb["l1_hit_rate"] < 1.0 and rb["issue"]["instructions_per_wave_segment"] > 500
     assert rep["x64"]["node_rounds_per_wave_segment"] > 1

@@ -65,7 +65,10 @@ def test_frame_bit_exact(gpu_scene, oracle_scene, W, H, spp, mrr, kw):
 # (a later slice finds the earlier one's sums in memory).
 SHIPPED_CASES = [(1, 1, 40, 8, {}), (7, 3, 30, 8, {}), (8, 9, 20, 8, {}), (9, 8, 20, 3, {}), (15, 5, 16, 8, {}), (16, 8, 16, 8, {}),
                  (17, 33, 8, 8, {"error": 0.001}), (31, 7, 12, 2, {}), (37, 19, 9, 8, {}), (96, 64, 6, 8, {}),
-                 (40, 24, 24, 8, {"error": 0.5}), (104, 50, 12, 8, {"error": 0.001, "seed": 7}), (250, 130, 5, 8, {"eps": 1e-3})]
+                 (40, 24, 24, 8, {"error": 0.5}), (104, 50, 12, 8, {"error": 0.001, "seed": 7}), (250, 130, 5, 8, {"eps": 1e-3}),
+                 # adaptive sampling deep into the passes where it bites: the two-pixel kernel compacts sparse passes
+                 (48, 40, 40, 8, {"error": 0.02}), (33, 17, 64, 4, {"error": 0.005, "seed": 3}), (64, 16, 30, 8, {"error": 0.5, "seed": 9}),
+                 (16, 8, 50, 8, {"error": 0.01})]
 
 
 @pytest.fixture(scope="module")

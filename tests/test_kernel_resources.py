@@ -35,9 +35,10 @@ def usage():
 
 # mangled name -> (what, waves per SIMD at least, LDS bytes at most)
 HOT = {
-    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("small scenes, two pixels per lane (the headline kernel)", 5, 8192),
-    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb1EEEvNS_10RenderArgsE": ("small scenes, one pixel per lane (small launches)", 6, 6826),
-    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 6, 6826),
+    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("small scenes, two pixels per lane (the headline kernel)", 5, 8192),
+    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb1EEEvNS_10RenderArgsE": ("the same with adaptive sampling on (compacts sparse passes)", 5, 8192),
+    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb1ELb0EEEvNS_10RenderArgsE": ("small scenes, one pixel per lane (small launches)", 6, 6826),
+    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 6, 6826),
 }
 
 

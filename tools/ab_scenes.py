@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--libs", default="hip")
     ap.add_argument("--scenes", default="tor,x64,x195")
     ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--error", type=float, default=-1.0, help="adaptive-sampling threshold (-ERR); negative = off")
     ap.add_argument("--order-modes", default="")
     ap.add_argument("--sweep", default="", help="test-hook knob and values, e.g. bvh_fill=0.6,0.75,1.0 (libpt_testhooks.so)")
     a = ap.parse_args()
@@ -54,7 +55,7 @@ def main():
             L.pt_test_set_mutation(knob.encode(), float(mode))
         for sn in a.scenes.split(","):
             sc = pt.Scene.load_obj(*scenes[sn], device=0, library=L)
-            p = pt.RenderParams(W, H, 0, H, 0, a.spp, 8, 1e-4, -1.0, 42)
+            p = pt.RenderParams(W, H, 0, H, 0, a.spp, 8, 1e-4, a.error, 42)
             ptrs = (buf.data_ptr(), buf.data_ptr() + 12 * W * H, buf.data_ptr() + 24 * W * H)
             st = sc.render_device(p, *ptrs, stream=stream.cuda_stream, want_stats=True)
             ms = []

@@ -28,7 +28,7 @@ P = os.path.join(ROOT, "profiles")
 
 def timed_instantiation(kernel_name):
     """integrate_kernel<SKY, BIG, STATS, ENV>: the timed launches are the statistics-free ones (third argument false)."""
-    m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)(?:,(\w+))?>", kernel_name.replace(" ", ""))
+    m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)(?:,(\w+))?(?:,(\w+))?>", kernel_name.replace(" ", ""))
     return bool(m) and m.group(3) == "false"
 
 
@@ -84,8 +84,8 @@ def main():
     ks = max(glob.glob(os.path.join(G, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(ks, os.path.join(P, f"{t}_kernel_stats.csv"))
     out = {}
-    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,false,false,false,false>)", True),
-                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,true,false,false,false>)", True)):
+    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,false,false,false,false,false>)", True),
+                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,true,false,false,false,false>)", True)):
         m = detail(os.path.join(G, name), timed)
         if m:
             out[label] = m
@@ -108,8 +108,8 @@ def main():
     import subprocess
     import sys
     mp = os.path.join(ROOT, "path-tracing_amd", "lib", "blockprof", "map.json")
-    for scene, kern in (("tor", "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE"),
-                        ("x64", "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0EEEvNS_10RenderArgsE")):
+    for scene, kern in (("tor", "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE"),
+                        ("x64", "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE")):
         cnt = os.path.join(G, f"blockprof_{scene}.{kern}.txt")
         log = os.path.join(G, f"blockprof_{scene}.log")
         if not (os.path.exists(cnt) and os.path.exists(mp) and os.path.exists(log)):
