@@ -357,3 +357,29 @@ def test_pinned_host_buffers_through_the_abi(gpu_scene):
         for p in ptrs:
             L.pt_host_free(p)
     L.pt_host_free(None)
+
+
+@pytest.mark.parametrize("instances,W,H,spp,kw", [(3, 48, 32, 200, {"error": 0.05}), (6, 32, 24, 160, {"error": 0.2, "seed": 5})],
+                         ids=["x3", "x6"])
+def test_compacted_adaptive_passes_on_scenes_with_several_trees(tmp_path, hooks_lib, instances, W, H, spp, kw):
+    """Adaptive sampling, two pixels per lane, on small scenes with several sphere-tree clusters (Tor.obj's torus 3 and 6 times
+    in the room: 782 / 1 550 triangles): passes with at most 64 traced pixels per tile run compacted (pt_kernels.hip
+    "Compaction"), a lane then traces another lane's pixel through every cluster loop, root round and tree walk -- the
+    oracle's bits all the same, for both tile widths."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_replicated_scene as M
+    d = str(tmp_path) + "/"
+    M.generate(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models"), d, "r.obj", instances)
+    o = O.Scene.load(d, "r.obj")
+    rs, rs2, rc, rst = O.render(o, W, H, spp, 8, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, **kw)
+    assert rst["samples_traced"] < 0.8 * W * H * spp        # the adaptive skip really bites (about 60 % of the pixels end up skipping)
+    for width_mode in (2.0, 1.0):
+        hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
+        try:
+            h = pt.Scene.load_obj(d, "r.obj", device=0, library=hooks_lib)
+            assert h.counts()[0] == o.n_tri <= 2048
+            s, s2, c, _ = h.render_host(W, H, spp, 8, want_stats=False, **kw)
+        finally:
+            hooks_lib.pt_test_set_mutation(b"reset", 0.0)
+        assert np.array_equal(c, rc) and _same(s, rs) and _same(s2, rs2), width_mode
