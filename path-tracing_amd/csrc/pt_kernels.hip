@@ -514,11 +514,6 @@ __device__ __forceinline__ unsigned long long brute_force_key(const RenderArgs &
 // ray slot is in use this pass; when it is not, everything per-ray about slot 1 is skipped by scalar branches and the segment
 // costs about what a one-ray-per-lane segment costs (PT_SLOT_ON).  Without DYN the guards fold away.
 #define PT_SLOT_ON(k) ((k) == 0 || k1_on)
-#ifdef PT_GUARD_MINOR_OFF
-#define PT_SLOT_ON2(k) true
-#else
-#define PT_SLOT_ON2(k) PT_SLOT_ON(k)
-#endif
 template <bool ENV, bool EMIS, bool DYN = false, class Lds, class Stats>
 __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const Ray (&q)[Lds::kRays], const bool (&live)[Lds::kRays],
                                             const bool (&in_envelope)[Lds::kRays], int lane, float eps, float (&best)[Lds::kRays],
@@ -548,7 +543,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        if (!PT_SLOT_ON2(k)) continue;
+        if (!PT_SLOT_ON(k)) continue;
         const int id = lane + 64 * k;
         lds.best[id] = ~0ull;
         lds.ray[0][id] = q[k].ox; lds.ray[1][id] = q[k].oy; lds.ray[2][id] = q[k].oz;
@@ -626,7 +621,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         uint32_t pos = n_pairs + excl;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            if (!PT_SLOT_ON2(k)) continue;
+            if (!PT_SLOT_ON(k)) continue;
             emit_bits(lds.pairs, pos, bits[k], tri0 | ((static_cast<uint32_t>(lane + 64 * k) | flag) << 24));
             pos += __builtin_popcount(bits[k]);
         }
@@ -644,7 +639,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         uint32_t cnt = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k)
-            if (PT_SLOT_ON2(k)) cnt += __builtin_popcount(bits[k]);
+            if (PT_SLOT_ON(k)) cnt += __builtin_popcount(bits[k]);
         const uint32_t incl = wave_scan_inclusive(cnt), total = wave_last(incl);
         if (total == 0) return;
         if (n_pairs + total > kPairQueue) drain_pairs(0);
@@ -658,7 +653,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             bool some = false;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                part[k] = PT_SLOT_ON2(k) ? bits[k] & (((1u << kSlice) - 1u) << lo) : 0u;
+                part[k] = PT_SLOT_ON(k) ? bits[k] & (((1u << kSlice) - 1u) << lo) : 0u;
                 pc2 += __builtin_popcount(part[k]);
                 some = some || part[k] != 0;
             }
@@ -686,11 +681,11 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         if (pend_open && tri0 >= pend_tri0 && tri0 + width <= pend_tri0 + 32u) {
 #pragma unroll
             for (int k = 0; k < R; ++k)
-                if (PT_SLOT_ON2(k)) pend[k] |= bits[k] << (tri0 - pend_tri0);
+                if (PT_SLOT_ON(k)) pend[k] |= bits[k] << (tri0 - pend_tri0);
         } else {
             flush_pending();
 #pragma unroll
-            for (int k = 0; k < R; ++k) pend[k] = PT_SLOT_ON2(k) ? bits[k] : 0u;
+            for (int k = 0; k < R; ++k) pend[k] = PT_SLOT_ON(k) ? bits[k] : 0u;
             pend_tri0 = tri0;
             pend_open = true;
         }
@@ -758,7 +753,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             auto push_top = [&](uint32_t top) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    if (!PT_SLOT_ON2(k)) continue;
+                    if (!PT_SLOT_ON(k)) continue;
                     while (__any(tmask[k] != 0)) {   // at most 8 x 64 R items > capacity: drained in the expansion loop before overflow
                         const bool has = tmask[k] != 0;
                         const unsigned long long ball = __ballot(has);
@@ -782,7 +777,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     pcb[k] = 0;
-                    if (!PT_SLOT_ON2(k)) continue;
+                    if (!PT_SLOT_ON(k)) continue;
                     pcb[k] = __ballot(pc[k]);
                     rcnt += __builtin_popcountll(pcb[k]);
                 }
@@ -796,7 +791,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                         uint32_t at = 0;   // the stack is empty here: the compacted ray ids go to its bottom
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
-                            if (!PT_SLOT_ON2(k)) continue;
+                            if (!PT_SLOT_ON(k)) continue;
                             if (pc[k]) lds.nodes[at + lanes_below(pcb[k])] = static_cast<uint32_t>(lane + 64 * k);
                             at += __builtin_popcountll(pcb[k]);
                         }
@@ -1151,7 +1146,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
     PT_STAMP(st, 5);   // exact rounds
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        if (!PT_SLOT_ON2(k)) {   // (nobody's ray)
+        if (!PT_SLOT_ON(k)) {   // (nobody's ray)
             hit[k] = -1;
             hit_rec[k] = a.exact;
             best[k] = __builtin_inff();
