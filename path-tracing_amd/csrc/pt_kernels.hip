@@ -73,6 +73,9 @@ struct SmallQueues2 { static constexpr int kNodeStack = PT_SMALL2_NODES, kPairQu
 #ifndef PT_BIG_EXACT_AT
 #define PT_BIG_EXACT_AT 64    // big scenes: pre-filtered pairs waiting before an exact round runs (fewer = earlier pruning, emptier rounds)
 #endif
+#ifndef PT_BOX_SPREAD
+#define PT_BOX_SPREAD 0       // 1: under-filled box-tree rounds spread a node's children over 2 / 4 / 8 lanes (measured: +-0 on the x64
+#endif                        // replica, -1 % on x195 -- the tail rounds wait for their node loads, not for issue slots; ab62)
 #ifndef PT_BIG_WAVES
 #define PT_BIG_WAVES (PT_WAVES_PER_SIMD - 2)   // waves per SIMD the big-scene and skybox instantiations are compiled for
 #endif
@@ -458,8 +461,11 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
 // instructions per node that clamping the component to 1e-30 cost.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return static_cast<float>((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
+// PER = 8: all children of the node.  PER = 4, 2, 1: the node's children are spread over 2, 4, 8 lanes (under-filled rounds) and
+// this lane tests children sub * PER ... sub * PER + PER - 1; the result has its bits at those positions.
+template <int PER = 8>
 __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
-                                                      float t_best, float err) {
+                                                      float t_best, float err, uint32_t sub = 0) {
     const float step = __uint_as_float((q0.w & 0xFFu) << 23);
     const float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
     const float ax = step * ix, ay = step * iy, az = step * iz;
@@ -473,12 +479,22 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
     // pick the byte rows of the entry (n) and exit (f) planes once per node.  q -> fma(A, q, B) is monotone, so
     // entry <= exit per axis holds in float arithmetic too.
     const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
-    const uint32_t nx0 = sx ? q2.z : q1.x, nx1 = sx ? q2.w : q1.y, fx0 = sx ? q1.x : q2.z, fx1 = sx ? q1.y : q2.w;
-    const uint32_t ny0 = sy ? q3.x : q1.z, ny1 = sy ? q3.y : q1.w, fy0 = sy ? q1.z : q3.x, fy1 = sy ? q1.w : q3.y;
-    const uint32_t nz0 = sz ? q3.z : q2.x, nz1 = sz ? q3.w : q2.y, fz0 = sz ? q2.x : q3.z, fz1 = sz ? q2.y : q3.w;
+    uint32_t nx0 = sx ? q2.z : q1.x, nx1 = sx ? q2.w : q1.y, fx0 = sx ? q1.x : q2.z, fx1 = sx ? q1.y : q2.w;
+    uint32_t ny0 = sy ? q3.x : q1.z, ny1 = sy ? q3.y : q1.w, fy0 = sy ? q1.z : q3.x, fy1 = sy ? q1.w : q3.y;
+    uint32_t nz0 = sz ? q3.z : q2.x, nz1 = sz ? q3.w : q2.y, fz0 = sz ? q2.x : q3.z, fz1 = sz ? q2.y : q3.w;
+    if constexpr (PER < 8) {
+        // this lane's children sit in one word per row (children 0-3 in the first, 4-7 in the second), from byte (sub * PER) & 3 on:
+        // bring them to byte 0 of the "first" words, so that the byte indices below stay compile-time constants
+        const uint32_t c0 = sub * PER;
+        const bool up = c0 >= 4u;
+        const uint32_t sh = 8u * (c0 & 3u);
+        nx0 = (up ? nx1 : nx0) >> sh; fx0 = (up ? fx1 : fx0) >> sh;
+        ny0 = (up ? ny1 : ny0) >> sh; fy0 = (up ? fy1 : fy0) >> sh;
+        nz0 = (up ? nz1 : nz0) >> sh; fz0 = (up ? fz1 : fz0) >> sh;
+    }
     uint32_t m = 0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < PER; ++c) {
         const int k = c & 3;
         const bool up = c >= 4;
         const float tnx = __builtin_fmaf(ax, byte_to_float(up ? nx1 : nx0, k), nbx), tfx = __builtin_fmaf(ax, byte_to_float(up ? fx1 : fx0, k), bx);
@@ -488,6 +504,7 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
         const float t_out = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, t_best));
         m |= !(t_in > t_out) ? (1u << c) : 0u;   // a NaN keeps
     }
+    if constexpr (PER < 8) m <<= sub * PER;
     return m;
 }
 
@@ -1066,10 +1083,17 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
             while (n_nodes > 0) {
                 ++st.w_node_rounds;
                 const uint32_t cnt = min(64u, n_nodes);
-                uint32_t m8 = 0, src = 0, base = 0;
-                bool leaf = false;
-                if (static_cast<uint32_t>(lane) < cnt) {
-                    const uint32_t e = lds.nodes[n_nodes - 1 - lane];
+                // (PT_BOX_SPREAD, off: a round with few items -- the tail of every walk: 1.3 of the x64 replica's 9.1 rounds per
+                // wave-segment hold at most 32 -- spreads each item's 8 children over 2, 4 or 8 lanes, like the sphere-tree walk)
+                uint32_t shift = PT_BOX_SPREAD ? (cnt <= 8u ? 3u : cnt <= 16u ? 2u : cnt <= 32u ? 1u : 0u) : 0u;
+                uint32_t m8, src, base, kids, keep, packed, incl, tot;
+                bool leaf;
+                for (;;) {
+                m8 = 0; src = 0; base = 0;
+                leaf = false;
+                const uint32_t item = static_cast<uint32_t>(lane) >> shift, sub = static_cast<uint32_t>(lane) & ((1u << shift) - 1u);
+                if (item < cnt) {
+                    const uint32_t e = lds.nodes[n_nodes - 1 - item];
                     src = e >> Lds::kNodeSrcShift;
                     const uint32_t node = e & ((1u << Lds::kNodeSrcShift) - 1u);
                     Ray r;
@@ -1083,21 +1107,26 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 #endif
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    m8 = box_children_kept(q0, q1, q2, q3, r, t_best, a.bvh_err);
+                    if (shift == 0u) m8 = box_children_kept<8>(q0, q1, q2, q3, r, t_best, a.bvh_err);
+                    else if (shift == 1u) m8 = box_children_kept<4>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
+                    else if (shift == 2u) m8 = box_children_kept<2>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
+                    else m8 = box_children_kept<1>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
                     m8 &= (2u << ((q0.w >> 8) & 7u)) - 1u;   // children that exist
                     leaf = node >= a.bvh_leaf0;
                     base = leaf ? (node - a.bvh_leaf0) * kFan : (q0.w >> 11);
                 }
-                uint32_t kids = __builtin_popcount(m8);
-                uint32_t keep = cnt;
+                kids = __builtin_popcount(m8);
+                keep = cnt;
                 // Children of inner nodes go back on the stack, triangles of leaves into the pair queue.  One prefix sum serves both
                 // (inner lanes count in the low half of the word, leaf lanes in the high half): its last lane says whether everything
                 // fits, its other lanes where each lane's entries go.
-                uint32_t packed = leaf ? kids << 16 : kids;
-                uint32_t incl = wave_scan_inclusive(packed);
-                uint32_t tot = wave_last(incl);
+                packed = leaf ? kids << 16 : kids;
+                incl = wave_scan_inclusive(packed);
+                tot = wave_last(incl);
                 if (n_pairs + (tot >> 16) > kPairQueue) drain_pairs(0);
-                if (!(n_pairs + (tot >> 16) <= kPairQueue && n_nodes - cnt + (tot & 0xFFFFu) <= kNodeStack)) {
+                if (n_pairs + (tot >> 16) <= kPairQueue && n_nodes - cnt + (tot & 0xFFFFu) <= kNodeStack) break;
+                if (shift != 0u) { shift = 0u; continue; }   // rare: redo the round one lane per item
+                {
                     // Rare: not everything fits.  Commit the longest prefix of lanes (= the top of the stack) whose children do;
                     // the top item always commits (its children are one level deeper; the 64 slots of slack absorb them).
                     const bool fits = static_cast<uint32_t>(lane) < cnt && n_pairs + (incl >> 16) <= kPairQueue &&
@@ -1111,6 +1140,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     packed = leaf ? kids << 16 : kids;
                     incl = wave_scan_inclusive(packed);
                     tot = wave_last(incl);
+                }
+                break;
                 }
                 n_nodes -= keep;
                 wave_sync();   // every lane has read its item before the stack is written
