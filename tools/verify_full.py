@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every segment of the full-size frames against the reference's all-triangles loop, beyond what the test suite runs:
 
-    python tools/verify_full.py [shipped]   ->  one line per frame (segments checked, mismatches, seconds)
+    python tools/verify_full.py [shipped] [only=<part of a frame's name>]   ->  one line per frame (segments checked, mismatches, seconds)
 
 Without an argument: libpt_verify.so (the statistics instantiations, full search on every segment).  `shipped`:
 libpt_verify_shipped.so -- the statistics-free instantiations a caller without pt_render_stats gets (two pixels per lane,
@@ -23,16 +23,22 @@ shipped = len(sys.argv) > 1 and sys.argv[1] == "shipped"
 L = pt.load_library(os.path.join(ROOT, "path-tracing_amd", "lib", "libpt_verify_shipped.so") if shipped else pt.VERIFY_LIB_PATH)
 L.pt_test_set_mutation(b"reset", 0.0)
 models = os.path.join(ROOT, "models") + "/"
-jobs = [("configs[2] Tor.obj 1920x1080x1024spp", models, "Tor.obj", 1920, 1080, 1024),
-        ("configs[3] Tor.obj 3840x2160x256spp", models, "Tor.obj", 3840, 2160, 256)]
+jobs = [("configs[2] Tor.obj 1920x1080x1024spp", models, "Tor.obj", 1920, 1080, 1024, -1.0),
+        ("configs[3] Tor.obj 3840x2160x256spp", models, "Tor.obj", 3840, 2160, 256, -1.0)]
+if shipped:   # the reference's default -ERR 0.001: the two-pixel kernel's adaptive instantiation, sparse passes compacted
+    jobs.append(("Tor.obj 1920x1080x512spp -ERR 0.001", models, "Tor.obj", 1920, 1080, 512, 0.001))
 d = tempfile.mkdtemp() + "/"
 for n, spp in ((64, 32), (195, 16)):
     M.generate(os.path.join(ROOT, "models"), d, f"x{n}.obj", n)
-    jobs.append((f"configs[4] x{n} replica 1920x1080x{spp}spp", d, f"x{n}.obj", 1920, 1080, spp))
-for name, dd, obj, W, H, spp in jobs:
+    jobs.append((f"configs[4] x{n} replica 1920x1080x{spp}spp", d, f"x{n}.obj", 1920, 1080, spp, -1.0))
+only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
+for name, dd, obj, W, H, spp, err in jobs:
+    if only and not any(o in name for o in only):
+        continue
     s = pt.Scene.load_obj(dd, obj, device=0, library=L)
     t = time.perf_counter()
-    st = s.render_host(W, H, spp, 8, error=-1.0)[3]
+    st = s.render_host(W, H, spp, 8, error=err)[3]
+    extra = f", {st['partial_commit_rounds']} compacted tile-passes" if shipped and err >= 0 else ""
     print(f"{name}: {st['verify_checked']} segments checked against all {st['n_triangles']} triangles, "
-          f"{st['verify_mismatches']} mismatches, {time.perf_counter() - t:.1f} s", flush=True)
+          f"{st['verify_mismatches']} mismatches{extra}, {time.perf_counter() - t:.1f} s", flush=True)
     s.close()
