@@ -210,6 +210,7 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.n_bvh = static_cast<uint32_t>(t.bvh.size());
     a.bvh_err = t.bvh_err;
     a.mats = scene->d_mats;
+    a.n_mats = static_cast<int32_t>(scene->shared->tables.mats.size());
     a.sky = scene->d_sky;
     a.sky_w = scene->d_sky ? scene->sky_w : 0;
     a.sky_h = scene->d_sky ? scene->sky_h : 0;

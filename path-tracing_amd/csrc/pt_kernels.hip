@@ -358,6 +358,11 @@ template <int N> struct AccPlanes { float v[7][N]; };
 template <> struct AccPlanes<0> {};
 template <int N> struct FlagWords { uint32_t v[N]; };
 template <> struct FlagWords<0> {};
+#ifndef PT_MATS_IN_LDS
+#define PT_MATS_IN_LDS 16   // two-pixel kernels: a scene's materials, if it has at most this many, are read from a copy in LDS
+#endif
+template <int N> struct MatCache { float4 v[3 * N]; };
+template <> struct MatCache<0> {};
 template <class Q, int R, bool FLAGS = false>
 struct WaveLds {
     static constexpr int kRays = R, kSlots = 64 * R;
@@ -387,6 +392,11 @@ struct WaveLds {
     // adaptive-sampling instantiation of the two-pixel kernel: the cached "variance is low" answer of the tile's pixels, by pixel
     // (lane + 64 k): another lane may be the one that traces a lane's second pixel, see "Compaction" in integrate_kernel
     FlagWords<FLAGS ? kSlots : 0> low;
+    // Shading reads the hit's record and then, through its material index, the material: two dependent loads.  The two-pixel
+    // kernels take the second from a copy in LDS when the scene has at most kMatCache materials (Tor.obj: 5): +0.8 % (256 spp:
+    // 73.2 -> 72.6 ms; with adaptive sampling +1.3 %); the box-tree kernel gains nothing from it (ab64) and does without.
+    static constexpr int kMatCache = (R == 2 && !kPrefilter) ? PT_MATS_IN_LDS : 0;
+    MatCache<kMatCache> mat;
 };
 struct WaveStats {
     uint32_t n_exact = 0, w_segments = 0, w_node_rounds = 0, w_exact_iters = 0, w_partial = 0;   // wave-uniform, live in SGPRs
@@ -1241,6 +1251,13 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R, ADAPT> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
+    if constexpr (decltype(lds)::kMatCache > 0) {
+        if (a.n_mats <= decltype(lds)::kMatCache) {
+            const float4 *src = reinterpret_cast<const float4 *>(a.mats);
+            for (int i = lane; i < 3 * a.n_mats; i += 64) lds.mat.v[i] = src[i];
+            wave_sync();
+        }
+    }
     // Work item = (pixel tile, chunk of passes), claimed from a ticket counter in chunk-major order: all tiles' first
     // chunk, then all tiles' second chunk, ...  Cutting the pass range into chunks gives the tail of the launch small
     // items to balance with (at 1080p x 64 spp one tile per wave left the last of 5.3 rounds a quarter full).
@@ -1661,9 +1678,21 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
                     const float4 pl = reinterpret_cast<const float4 *>(rec)[0];
                     const int mi = rec->material;
                     const float px = q[k].ox + q[k].dx * best[k], py = q[k].oy + q[k].dy * best[k], pz = q[k].oz + q[k].dz * best[k];
-                    const float4 m0v = reinterpret_cast<const float4 *>(a.mats + mi)[0];   // kd, chance0
-                    const float4 m1v = reinterpret_cast<const float4 *>(a.mats + mi)[1];   // ks, chance1
-                    const int4 m2v = reinterpret_cast<const int4 *>(a.mats + mi)[2];       // n_lobes, kind0, kind1
+                    float4 m0v, m1v;   // kd, chance0; ks, chance1
+                    int4 m2v;          // n_lobes, kind0, kind1
+                    bool mat_cached = false;
+                    if constexpr (decltype(lds)::kMatCache > 0) mat_cached = a.n_mats <= decltype(lds)::kMatCache;
+                    if (mat_cached) {
+                        if constexpr (decltype(lds)::kMatCache > 0) {
+                            m0v = lds.mat.v[3 * mi]; m1v = lds.mat.v[3 * mi + 1];
+                            const float4 t = lds.mat.v[3 * mi + 2];
+                            m2v = make_int4(__float_as_int(t.x), __float_as_int(t.y), __float_as_int(t.z), __float_as_int(t.w));
+                        }
+                    } else {
+                        m0v = reinterpret_cast<const float4 *>(a.mats + mi)[0];
+                        m1v = reinterpret_cast<const float4 *>(a.mats + mi)[1];
+                        m2v = reinterpret_cast<const int4 *>(a.mats + mi)[2];
+                    }
                     // On a path's last segment the random words only matter where they choose between an emissive lobe and
                     // another one (see below: nothing else of that segment survives it).
                     uint32_t w0 = 0, w1 = 0, w2 = 0, w3;

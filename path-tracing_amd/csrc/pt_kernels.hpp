@@ -22,6 +22,7 @@ struct RenderArgs {
     uint32_t bvh_leaf0, n_bvh;    // first leaf node, number of nodes
     float bvh_err;            // relative rounding allowance of the slab arithmetic
     const MatRec *mats;
+    int32_t n_mats;
     const uint8_t *sky;       // skybox texels (B,G,R bytes, top-down rows) or nullptr
     int32_t sky_w, sky_h;
     float *sum, *sum2;        // row band, 3 floats per pixel

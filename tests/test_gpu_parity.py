@@ -383,3 +383,63 @@ def test_compacted_adaptive_passes_on_scenes_with_several_trees(tmp_path, hooks_
         finally:
             hooks_lib.pt_test_set_mutation(b"reset", 0.0)
         assert np.array_equal(c, rc) and _same(s, rs) and _same(s2, rs2), width_mode
+
+
+def _tor_with_materials(tmp, n_mats):
+    """Tor.obj with `n_mats` materials: copies of its five (material i is a tinted copy of material i % 5, so the light stays a
+    light), the faces of every `usemtl` run dealt out over the copies."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blocks = open(os.path.join(root, "models", "Tor.mtl")).read().split("newmtl ")[1:]
+    base = {}
+    for b in blocks:
+        lines = b.strip().split("\n")
+        base[int(lines[0])] = lines[1:]
+    mtl = []
+    for i in range(n_mats):
+        mtl.append(f"newmtl {i}")
+        for ln in base[i % 5]:
+            tok = ln.split()
+            if tok and tok[0] == "Kd":
+                tint = 1.0 - 0.03 * (i // 5)
+                ln = "Kd " + " ".join(f"{float(v) * tint:.6f}" for v in tok[1:])
+            mtl.append(ln)
+        mtl.append("")
+    d = str(tmp) + "/"
+    open(d + "m.mtl", "w").write("\n".join(mtl))
+    out, cur, k = [], 0, 0
+    for ln in open(os.path.join(root, "models", "Tor.obj")).read().split("\n"):
+        tok = ln.split()
+        if tok and tok[0] == "mtllib":
+            out.append("mtllib m.mtl")
+        elif tok and tok[0] == "usemtl":
+            cur = int(tok[1])
+        elif tok and tok[0] == "f":
+            copies = [i for i in range(n_mats) if i % 5 == cur]
+            out.append(f"usemtl {copies[k % len(copies)]}")
+            out.append(ln)
+            k += 1
+        else:
+            out.append(ln)
+    open(d + "m.obj", "w").write("\n".join(out))
+    return d
+
+
+@pytest.mark.parametrize("n_mats", [16, 17, 40])
+def test_material_counts_around_the_lds_copy(tmp_path, hooks_lib, n_mats):
+    """The two-pixel kernels read a scene's materials from a copy in LDS if it has at most 16 of them, from memory otherwise:
+    16 (the last count that fits), 17 and 40 materials, both tile widths, adaptive sampling on and off -- the oracle's bits."""
+    d = _tor_with_materials(tmp_path, n_mats)
+    o = O.Scene.load(d, "m.obj")
+    assert len(o.materials()) == n_mats
+    for kw in ({}, {"error": 0.02}):
+        W, H, spp = 48, 24, 40
+        rs, rs2, rc, _ = O.render(o, W, H, spp, 8, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, **kw)
+        assert rc.sum() > 0
+        for width_mode in (2.0, 1.0):
+            hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
+            try:
+                h = pt.Scene.load_obj(d, "m.obj", device=0, library=hooks_lib)
+                s, s2, c, _ = h.render_host(W, H, spp, 8, want_stats=False, **kw)
+            finally:
+                hooks_lib.pt_test_set_mutation(b"reset", 0.0)
+            assert np.array_equal(c, rc) and _same(s, rs) and _same(s2, rs2), (kw, width_mode)
