@@ -83,7 +83,7 @@ def walk(tree, root, quant=True):
             his = nlo + np.ceil((his - nlo) / step) * step
         for c, lo, hi in zip(ch, los, his):
             k = slab(lo, hi, RO[rays], RD[rays], RT[rays] * (1 + 1e-6))
-            if c[0]: pairs[rays[k]] += 1
+            if c[0]: pairs[rays[k]] += c[1]
             else: stack.append((c[1], rays[k]))
     return visits, pairs, tests
 
@@ -98,7 +98,7 @@ for n in range(nn):
         if n >= fl:
             s = (n - fl) * 8 + c
             if st[s] < 0: continue
-            ch.append((True, int(st[s]), lo, hi))
+            ch.append((True, 1, lo, hi))
         else:
             ch.append((False, int(nodes["base"][n]) + c, lo, hi))
     T0.child.append(ch)
@@ -129,7 +129,7 @@ def build_bin(ids, leaf_max):
     return n
 SAHQ = False
 sys.setrecursionlimit(100000)
-for leaf_max in (8, 4):
+for leaf_max in (8, 16):
     t0 = time.time()
     root = build_bin(np.array(sorted(small)), leaf_max)
     # collapse: every wide node takes the binary node's children and keeps replacing the child of largest area by its two
@@ -138,7 +138,12 @@ for leaf_max in (8, 4):
     def collapse(bn):
         me = len(W.child); W.child.append(None)
         if bn.l is None:
-            W.child[me] = [(True, int(t), tlo[t], thi[t]) for t in bn.ids]
+            if leaf_max > 8:   # wide leaves: 8 child boxes of (up to) leaf_max / 8 triangles each, neighbours along the leaf's longest axis
+                ids = np.array(bn.ids); ax = int(np.argmax(bn.hi - bn.lo)); ids = ids[np.argsort(cen[ids, ax], kind="stable")]
+                per = (len(ids) + 7) // 8
+                W.child[me] = [(True, len(g), tlo[g].min(0), thi[g].max(0)) for g in (ids[i:i + per] for i in range(0, len(ids), per))]
+            else:
+                W.child[me] = [(True, 1, tlo[t], thi[t]) for t in bn.ids]
             return me
         kids = [bn.l, bn.r]
         while len(kids) < 8:
