@@ -1,4 +1,9 @@
-// Micro-benchmark: how many 16-byte gather loads per clock can one CU's vector L1 serve?
+// Micro-benchmark: how many gather requests per clock does one compute unit's vector L1 serve?  (profiles/r03_ab_logs.txt ab63)
+//   hipcc --offload-arch=gfx950 -O3 -o l1_gather_rate tools/l1_gather_rate.hip && ./l1_gather_rate
+// 24 waves per CU walk a table of 64-byte nodes with data-dependent indices (like a tree walk) in six access patterns:
+//   0  one 16-byte load per lane and step            3  a quad reads ONE node, each lane another quarter (coalesced 64 bytes)
+//   1  four 16-byte loads of the lane's own node     4  one 4-byte load per lane and step
+//   2  four lanes share a node, numbers by ds_bpermute   5  quads read four nodes in four instructions, node numbers by DPP
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
