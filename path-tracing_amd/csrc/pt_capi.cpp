@@ -56,12 +56,12 @@ namespace {
 
 // The layouts the kernels read pack indices into bit fields; a hierarchy that does not fit them must be refused, never
 // truncated: (ray, slot) pairs keep the slot in 24 bits (pt_kernels.hip: `e & 0xFFFFFF`), a box-tree node keeps its child
-// base in 21 bits (BvhNode::meta, `base << 11`; stack entries have 26), a sphere tree has at most kMaxLevels levels.
+// base in 20 bits (BvhNode::meta, `base << 12`: a child node, or a leaf's first slot / 8 -- fewer leaves than nodes; stack entries have 26), a sphere tree has at most kMaxLevels levels.
 int check_table_limits(unsigned long long n_slots, unsigned long long n_bvh_nodes, long long n_levels) {
     if (n_slots >= (1ull << 24))
         return fail(PT_ERR_UNSUPPORTED, "the culling hierarchy has " + std::to_string(n_slots) + " slots; (ray, slot) work items hold 24 bits");
-    if (n_bvh_nodes >= (1ull << 21))
-        return fail(PT_ERR_UNSUPPORTED, "the box tree has " + std::to_string(n_bvh_nodes) + " nodes; a node's child base holds 21 bits");
+    if (n_bvh_nodes >= (1ull << 20))
+        return fail(PT_ERR_UNSUPPORTED, "the box tree has " + std::to_string(n_bvh_nodes) + " nodes; a node's child base holds 20 bits");
     if (n_levels > pt::kMaxLevels)
         return fail(PT_ERR_UNSUPPORTED, "a sphere tree has " + std::to_string(n_levels) + " levels; the walk holds " + std::to_string(pt::kMaxLevels));
     return PT_OK;
@@ -1067,6 +1067,7 @@ int pt_test_set_mutation(const char *family, double value) {
     else if (f == "emis_drop") m.emis_drop = value != 0;
     else if (f == "order_mode") m.order_mode = static_cast<int>(value);
     else if (f == "bvh_fill") m.bvh_fill = value;
+    else if (f == "bvh_mode") m.bvh_mode = static_cast<int>(value);
     else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);
     else if (f == "tile_width") g_force_tile_width = static_cast<int>(value);
     else return fail(PT_ERR_INVALID_ARGUMENT, "unknown mutation family " + f);

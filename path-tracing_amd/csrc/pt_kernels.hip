@@ -1122,8 +1122,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     else if (shift == 2u) m8 = box_children_kept<2>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
                     else m8 = box_children_kept<1>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
                     m8 &= (2u << ((q0.w >> 8) & 7u)) - 1u;   // children that exist
-                    leaf = node >= a.bvh_leaf0;
-                    base = leaf ? (node - a.bvh_leaf0) * kFan : (q0.w >> 11);
+                    leaf = ((q0.w >> 11) & 1u) != 0u;                       // BvhNode::meta
+                    base = leaf ? (q0.w >> 12) * kFan : (q0.w >> 12);      // a leaf's first slot / an inner node's first child
                 }
                 kids = __builtin_popcount(m8);
                 keep = cnt;

@@ -74,7 +74,8 @@ static const uint32_t kNoTriangle = 0xFFFFFFFFu;
 // Child boxes are rounded OUTWARD, so a dequantised box always contains the true one.
 struct BvhNode {
     float org[3];
-    uint32_t meta;       // biased exponent of the step (bits 0-7) | children - 1 (bits 8-10) | child_base (bits 11-31)
+    uint32_t meta;       // biased exponent of the step (bits 0-7) | children - 1 (bits 8-10) | leaf (bit 11) | base (bits 12-31):
+                         // inner node: index of its first child node (children are consecutive); leaf: first slot / 8
     uint8_t lo[3][8];    // per axis, per child: lower bound in steps from org
     uint8_t hi[3][8];    // upper bound
 };
@@ -140,7 +141,8 @@ struct CullMutation {
     int no_absorb = 0;
     int emis_drop = 0;                // table builder: 1 = the lowest emitter bit of the large class is cleared (a WRONG table: negative control)
     int no_last_segment_filter = 0;   // integrator: 1 = a path's last segment searches all triangles like every other segment
-    double bvh_fill = 0.5;    // box tree: target fill of a node's children (builder tuning)
+    double bvh_fill = 0.5;    // box tree: target fill of a node's children (builder tuning; uniform-depth builder)
+    int bvh_mode = -1;        // box tree builder: -1 = the library's default, 0 = uniform depth, 1 = binary SAH collapsed to 8-wide nodes
     int order_mode = 0;   // small-scene clusters: 0 = cheaper of (cells, patches), 1 = as filed, 2 = cells, 3 = patches
 };
 extern CullMutation g_cull_mutation;

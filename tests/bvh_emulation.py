@@ -16,10 +16,11 @@ def decode(nodes):
     meta = raw[:, 12:16].copy().view(np.uint32).reshape(-1)
     step = ((meta & 0xFF).astype(np.uint32) << 23).view(np.float32)
     count = ((meta >> 8) & 7) + 1
-    base = meta >> 11
+    leaf = ((meta >> 11) & 1).astype(bool)
+    base = meta >> 12          # inner node: first child node; leaf: first slot / 8
     lo = raw[:, 16:40].reshape(-1, 3, 8)
     hi = raw[:, 40:64].reshape(-1, 3, 8)
-    return {"org": org, "step": step, "count": count, "base": base, "lo": lo, "hi": hi}
+    return {"org": org, "step": step, "count": count, "base": base, "leaf": leaf, "lo": lo, "hi": hi}
 
 
 def fma(a, b, c):
@@ -56,7 +57,9 @@ def parents(t, first_leaf):
     n = len(t["count"])
     par = np.full(n, -1, np.int64)
     pos = np.zeros(n, np.int64)
-    for i in range(first_leaf):
+    for i in range(n):
+        if t["leaf"][i]:
+            continue
         for c in range(int(t["count"][i])):
             par[int(t["base"][i]) + c] = i
             pos[int(t["base"][i]) + c] = c

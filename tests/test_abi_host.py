@@ -136,12 +136,12 @@ def test_cli_fails_loudly_without_gpu(models_dir, tmp_path):
 
 
 def test_table_limits_are_refused_not_truncated(tmp_path):
-    """The kernels pack a slot into 24 bits of a (ray, slot) pair and a box-tree node's child base into 21 bits of
+    """The kernels pack a slot into 24 bits of a (ray, slot) pair and a box-tree node's child base into 20 bits of
     BvhNode::meta; a hierarchy beyond either must be refused (synthetic counts: no 16 M-triangle scene needed)."""
     L = pt.lib()
-    assert L.pt_table_limits_check((1 << 24) - 1, (1 << 21) - 1, 8) == pt.PT_OK
+    assert L.pt_table_limits_check((1 << 24) - 1, (1 << 20) - 1, 8) == pt.PT_OK
     assert L.pt_table_limits_check(1 << 24, 10, 3) == 7 and b"24 bits" in L.pt_last_error()          # PT_ERR_UNSUPPORTED
-    assert L.pt_table_limits_check(1000, 1 << 21, 3) == 7 and b"21 bits" in L.pt_last_error()
+    assert L.pt_table_limits_check(1000, 1 << 20, 3) == 7 and b"20 bits" in L.pt_last_error()
     assert L.pt_table_limits_check(1000, 10, 9) == 7 and b"levels" in L.pt_last_error()
     # what the builder produces for a scene of the size class the advisor worried about stays far inside: slots per triangle
     # and nodes per triangle of the biggest scene of the suite

@@ -233,21 +233,28 @@ def test_hierarchy_does_not_depend_on_the_file_order(tmp_path, models_dir, tor):
     assert np.array_equal(perm[sb], sa)                                                       # ... i.e. the same triangle
 
 
-def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path):
+@pytest.mark.parametrize("bvh_mode", [0, 1], ids=["uniform-depth", "sah-collapsed"])
+def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path, bvh_mode, request):
     """Big scenes: the chain of box-tree nodes above the triangle the reference hits survives the kernel's slab test
-    (numpy restatement in float32, tests/bvh_emulation.py) for the tightest t_best the walk can hold: the hit's own t."""
+    (numpy restatement in float32, tests/bvh_emulation.py) for the tightest t_best the walk can hold: the hit's own t.
+    Both tree builders (pt_scene.cpp: build_bvh, build_bvh_sah), chosen through the test-hook build."""
     import bvh_emulation as B
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_replicated_scene as M
     d = str(tmp_path) + "/"
     n_tri = M.generate(os.path.join(ROOT, "models"), d, "x9.obj", 9)
     assert n_tri > 2048
-    g = pt.Scene.load_obj(d, "x9.obj", device=-1)
+    hooks = pt.load_library(pt.TESTHOOKS_LIB_PATH)
+    hooks.pt_test_set_mutation(b"reset", 0.0)
+    hooks.pt_test_set_mutation(b"bvh_mode", float(bvh_mode))     # (the test-hook build rebuilds the hierarchy at every call:
+    request.addfinalizer(lambda: hooks.pt_test_set_mutation(b"reset", 0.0))   # the knob stays set until the test is over)
+    g = pt.Scene.load_obj(d, "x9.obj", device=-1, library=hooks)
     o = O.Scene.load(d, "x9.obj")
     lay = g.cull_layout()
     t, fl = B.decode(lay["bvh"]), lay["bvh_first_leaf"]
     st = lay["slot_triangle"]
     assert len(lay["bvh"]) > fl > 0 and sorted(st[st >= 0]) == list(range(n_tri))
+    assert (len(lay["bvh"]), fl) == ((491, 65) if bvh_mode == 0 else (516, 110))     # (the two builders' trees for this scene)
     n_tree_slots = (len(lay["bvh"]) - fl) * 8
     assert (st[n_tree_slots:] >= 0).all()                          # padding only inside the tree's leaves
     par, pos = B.parents(t, fl)
@@ -270,7 +277,10 @@ def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path):
     ok &= slot_of[np.maximum(hi, 0)] < n_tree_slots                 # hits on triangles of the tree (not the walls)
     ro, rd, tb, sl = src[ok], dd[ok], ht[ok], slot_of[hi[ok]]
     assert len(sl) > 10000
-    node, child = fl + sl // 8, sl % 8
+    leaf_of_group = np.full(n_tree_slots // 8, -1)                  # leaf node that holds slots 8 g ... 8 g + 7
+    leaf_of_group[t["base"][t["leaf"]]] = np.flatnonzero(t["leaf"])
+    assert (leaf_of_group >= 0).all() and t["leaf"].sum() == len(lay["bvh"]) - fl
+    node, child = leaf_of_group[sl // 8], sl % 8
     levels = 0
     while len(node):
         kept = B.children_kept(t, node, ro, rd, tb, 5e-7)

@@ -95,8 +95,8 @@ for n in range(nn):
     for c in range(int(nodes["count"][n])):
         lo = nodes["org"][n].astype(np.float64) + nodes["lo"][n][:, c].astype(np.float64) * float(nodes["step"][n])
         hi = nodes["org"][n].astype(np.float64) + nodes["hi"][n][:, c].astype(np.float64) * float(nodes["step"][n])
-        if n >= fl:
-            s = (n - fl) * 8 + c
+        if nodes["leaf"][n]:
+            s = int(nodes["base"][n]) * 8 + c
             if st[s] < 0: continue
             ch.append((True, 1, lo, hi))
         else:
