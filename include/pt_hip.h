@@ -251,7 +251,7 @@ int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clu
                          float *constants);
 
 /* The order in which the hierarchy lists the triangles ("slots": the table builder groups triangles spatially, so the
- * hierarchy does not depend on the file order).  counts[4] = slots, box-tree nodes, first leaf node, clusters;
+ * hierarchy does not depend on the file order).  counts[4] = slots, box-tree nodes, inner nodes among them (the others are leaves of 8 slots each), clusters;
  * slot_triangle[k] = original triangle index of slot k, or -1 for a padding slot; bvh_nodes = the box tree of a big
  * scene, 64 bytes per node (path-tracing_amd/csrc/pt_scene.hpp: BvhNode).  Pass NULL to skip either.
  * In pt_scene_cull_tables the cluster fields first_tri / n_tri are slot ranges. */

@@ -270,7 +270,7 @@ class Scene:
         st = np.zeros(counts[0], np.int32)
         nodes = np.zeros((counts[1], 64), np.uint8)
         _check(self._L.pt_scene_cull_layout(self._h, eps, _ip(counts), _ip(st), nodes.ctypes.data_as(C.c_void_p)), self._L)
-        return {"slot_triangle": st, "bvh": nodes, "bvh_first_leaf": int(counts[2]), "clusters": int(counts[3])}
+        return {"slot_triangle": st, "bvh": nodes, "bvh_inner_nodes": int(counts[2]), "clusters": int(counts[3])}
 
     def trace_rays(self, origins, directions, eps=1e-4):
         """Closest hit per ray (scene.cpp:114-120).  directions must be unit length (normalised as ray.h:23 does)."""

@@ -206,7 +206,6 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.exact = scene->d_exact;
     a.exact_slot = scene->cull.exact_slot;
     a.bvh = scene->cull.bvh;
-    a.bvh_leaf0 = t.bvh_leaf0;
     a.n_bvh = static_cast<uint32_t>(t.bvh.size());
     a.bvh_err = t.bvh_err;
     a.mats = scene->d_mats;
@@ -770,7 +769,7 @@ static int scene_cull_layout_impl(pt_scene *scene, float eps, int32_t *counts, i
     const pt::CullTables &t = *tp;
     counts[0] = static_cast<int32_t>(t.slot_tri.size());
     counts[1] = static_cast<int32_t>(t.bvh.size());
-    counts[2] = static_cast<int32_t>(t.bvh_leaf0);
+    counts[2] = static_cast<int32_t>(t.bvh_inner);
     counts[3] = static_cast<int32_t>(t.clusters.size());
     if (slot_triangle)
         for (size_t k = 0; k < t.slot_tri.size(); ++k) slot_triangle[k] = t.slot_tri[k] == pt::kNoTriangle ? -1 : static_cast<int32_t>(t.slot_tri[k]);

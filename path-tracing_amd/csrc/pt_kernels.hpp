@@ -19,7 +19,7 @@ struct RenderArgs {
     const ExactRec *exact;    // n_tri records in the ORIGINAL triangle order: shading, the reference's all-triangles loop
     const ExactRec *exact_slot;   // the same records in slot order, `orig` = original index: the exact test of (ray, slot) pairs
     const BvhNode *bvh;       // big scenes: box tree over the small triangles, else nullptr
-    uint32_t bvh_leaf0, n_bvh;    // first leaf node, number of nodes
+    uint32_t n_bvh;           // number of nodes
     float bvh_err;            // relative rounding allowance of the slab arithmetic
     const MatRec *mats;
     int32_t n_mats;

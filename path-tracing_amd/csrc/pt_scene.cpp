@@ -608,7 +608,7 @@ void quantise_node(BvhNode &q, const Box &nb, const std::vector<Box> &kids, bool
 void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::vector<Centroid> &cen, std::vector<int> ids,
                double eps_line, CullTables &out, std::vector<int> &order) {
     out.bvh.clear();
-    out.bvh_leaf0 = 0;
+    out.bvh_inner = 0;
     out.bvh_err = static_cast<float>(5.0e-7 * PT_MUT(box_err));   // first-order worst case 3.6e-7 (tests/test_cull_margins_host.py)
     const size_t n = ids.size();
     if (n == 0) return;
@@ -657,7 +657,7 @@ void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::ve
     std::vector<size_t> level_first(top + 2, 0);
     size_t total = 0;
     for (int L = top; L >= 1; --L) { level_first[L] = total; total += levels[L].size(); }
-    out.bvh_leaf0 = static_cast<uint32_t>(level_first[1]);
+    out.bvh_inner = static_cast<uint32_t>(level_first[1]);
     out.bvh.resize(total);
     std::vector<Box> node_box(total, kEmptyBox);
     std::vector<std::vector<Box>> kid_box(total);
@@ -706,7 +706,7 @@ void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::ve
 void build_bvh_sah(const HostScene &s, const std::vector<TriGeo> &geo, const std::vector<Centroid> &cen, std::vector<int> ids,
                    double eps_line, CullTables &out, std::vector<int> &order) {
     out.bvh.clear();
-    out.bvh_leaf0 = 0;
+    out.bvh_inner = 0;
     out.bvh_err = static_cast<float>(5.0e-7 * PT_MUT(box_err));
     const size_t n = ids.size();
     if (n == 0) return;
@@ -867,7 +867,7 @@ void build_bvh_sah(const HostScene &s, const std::vector<TriGeo> &geo, const std
         const bool leaf = wide_kids[w].empty();
         quantise_node(out.bvh[w], node_box[w], kid_box[w], leaf, leaf ? leaf_slot[w] : first_child[w]);
     }
-    out.bvh_leaf0 = static_cast<uint32_t>(total - n_leaves);   // (leaves are not the last nodes here: only the COUNT of inner nodes)
+    out.bvh_inner = static_cast<uint32_t>(total - n_leaves);
 }
 
 }  // namespace

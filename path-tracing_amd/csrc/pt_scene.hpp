@@ -120,7 +120,7 @@ struct CullTables {
     CullConstants cc_all;            // its margins (they must cover the smallest triangle of the scene)
     std::vector<ClusterDesc> clusters;
     std::vector<BvhNode> bvh;        // big scenes only: box tree over the small triangles (slots [0, 8 * leaves))
-    uint32_t bvh_leaf0 = 0;          // index of the first leaf node
+    uint32_t bvh_inner = 0;          // inner nodes of the box tree (the other nodes are leaves: 8 slots each)
     float bvh_err = 0;               // relative rounding allowance of the kernel's slab arithmetic
     CullConstants cc;
     float eps = 0;

@@ -251,7 +251,7 @@ def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path, bvh_mode, request)
     g = pt.Scene.load_obj(d, "x9.obj", device=-1, library=hooks)
     o = O.Scene.load(d, "x9.obj")
     lay = g.cull_layout()
-    t, fl = B.decode(lay["bvh"]), lay["bvh_first_leaf"]
+    t, fl = B.decode(lay["bvh"]), lay["bvh_inner_nodes"]
     st = lay["slot_triangle"]
     assert len(lay["bvh"]) > fl > 0 and sorted(st[st >= 0]) == list(range(n_tri))
     assert (len(lay["bvh"]), fl) == ((491, 65) if bvh_mode == 0 else (516, 110))     # (the two builders' trees for this scene)
@@ -302,7 +302,7 @@ def test_big_scene_keeps_its_few_emitters_in_the_large_class(tmp_path, models_di
     def large_class(scene):
         lay = scene.cull_layout()
         st = lay["slot_triangle"]
-        return set(int(t) for t in st[(len(lay["bvh"]) - lay["bvh_first_leaf"]) * 8:] if t >= 0)
+        return set(int(t) for t in st[(len(lay["bvh"]) - lay["bvh_inner_nodes"]) * 8:] if t >= 0)
     light = large_class(pt.Scene.load_obj(d, "x9.obj", device=-1))
     assert len(light) == 14 and all(t >= n_tri - 14 for t in light)          # the room: 12 wall triangles and the light's 2
     # the same scene with an emissive torus material: 2 + 9 * 256 emitters, none of them moved

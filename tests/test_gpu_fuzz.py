@@ -96,7 +96,7 @@ def test_random_scene(tmp_path, seed, n_small, n_large, n_dup, few_emitters):
     if few_emitters and n > 2048:      # the box-tree kernel's last-segment test is on: every emitter sits in the large class
         emitters = set(np.flatnonzero((o.materials()[tri_mat, 3:6] != 0).any(1)).tolist())
         lay = g.cull_layout()
-        large = set(int(t) for t in lay["slot_triangle"][(len(lay["bvh"]) - lay["bvh_first_leaf"]) * 8:] if t >= 0)
+        large = set(int(t) for t in lay["slot_triangle"][(len(lay["bvh"]) - lay["bvh_inner_nodes"]) * 8:] if t >= 0)
         assert 0 < len(emitters) <= 8 and emitters <= large
     v = tri[:, 4:13].reshape(-1, 3, 3)
     m = 60_000

@@ -61,7 +61,7 @@ def test_frames_equal_the_oracle_for_every_path_length(tmp_path, models_dir, tor
     hooks.pt_test_set_mutation(b"reset", 0.0)
     W, H, spp = (96, 64, 6) if not replicas else (64, 48, 4)
     if replicas:      # the light sits in the large class exactly when it is the scene's only emitter
-        n_large = int((g.cull_layout()["slot_triangle"][(len(g.cull_layout()["bvh"]) - g.cull_layout()["bvh_first_leaf"]) * 8:] >= 0).sum())
+        n_large = int((g.cull_layout()["slot_triangle"][(len(g.cull_layout()["bvh"]) - g.cull_layout()["bvh_inner_nodes"]) * 8:] >= 0).sum())
         assert n_large == (14 if light_emits and not torus_emits else 12)
     contributing = 0
     for mrr in (1, 2, 3, 8):

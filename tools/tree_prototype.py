@@ -25,10 +25,10 @@ o = O.Scene.load(d, "s.obj")
 tri, _ = g.triangles()
 lay = g.cull_layout()
 st = lay["slot_triangle"]
-nodes = B.decode(lay["bvh"]); fl = lay["bvh_first_leaf"]
+nodes = B.decode(lay["bvh"]); fl = lay["bvh_inner_nodes"]
 n_slots_bvh = (len(lay["bvh"]) - fl) * 8
 small = st[:n_slots_bvh]; small = small[small >= 0]
-print("triangles", len(tri), "in tree", len(small), "nodes", len(lay["bvh"]), "first leaf", fl)
+print("triangles", len(tri), "in tree", len(small), "nodes", len(lay["bvh"]), "inner nodes", fl)
 V = tri[:, 4:13].reshape(-1, 3, 3).astype(np.float64)
 tlo, thi = V.min(1) - 1e-4, V.max(1) + 1e-4
 
