@@ -361,6 +361,8 @@ template <> struct FlagWords<0> {};
 #ifndef PT_MATS_IN_LDS
 #define PT_MATS_IN_LDS 16   // two-pixel kernels: a scene's materials, if it has at most this many, are read from a copy in LDS
 #endif
+template <int N> struct InvPlanes { float v[3][N]; };
+template <> struct InvPlanes<0> {};
 template <int N> struct MatCache { float4 v[3 * N]; };
 template <> struct MatCache<0> {};
 template <class Q, int R, bool FLAGS = false>
@@ -380,6 +382,9 @@ struct WaveLds {
     uint32_t filtered[Q::kFiltered];   // pairs that survived the pre-filter, waiting for a full exact round
     unsigned long long best[kSlots];   // per ray: (order-preserving bits of t) << 32 | triangle index; smaller is closer
     float ray[6][kSlots];          // this segment's rays, readable by every lane
+    // big scenes: 1 / direction of every ray, taken once per segment instead of at every node visit (three quarter-rate v_rcp_f32
+    // per visit, six visits per ray: +1.4 % / +0.9 % on the replicas, ab68)
+    InvPlanes<kPrefilter ? kSlots : 0> rinv;
     uint32_t nodes[kNodeStack + 64];// LIFO of tree nodes to expand (layout above; the box tree: ray << 26 | node)
     uint32_t pairs[kPairQueue];    // (ray, triangle) work items
     uint32_t level_off[kMaxLevels];// sphere offset of each level of the cluster being walked
@@ -475,9 +480,9 @@ __device__ __forceinline__ float byte_to_float(uint32_t w, int k) { return stati
 // this lane tests children sub * PER ... sub * PER + PER - 1; the result has its bits at those positions.
 template <int PER = 8>
 __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
-                                                      float t_best, float err, uint32_t sub = 0) {
+                                                      float ix, float iy, float iz, float t_best, float err, uint32_t sub = 0) {
+    // ix, iy, iz = v_rcp_f32 of the ray's direction components (the caller holds them per ray)
     const float step = __uint_as_float((q0.w & 0xFFu) << 23);
-    const float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
     const float ax = step * ix, ay = step * iy, az = step * iz;
     const float bx = (__uint_as_float(q0.x) - r.ox) * ix, by = (__uint_as_float(q0.y) - r.oy) * iy, bz = (__uint_as_float(q0.z) - r.oz) * iz;
     const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx), __builtin_fabsf(by)), __builtin_fabsf(bz));
@@ -575,6 +580,9 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         lds.best[id] = ~0ull;
         lds.ray[0][id] = q[k].ox; lds.ray[1][id] = q[k].oy; lds.ray[2][id] = q[k].oz;
         lds.ray[3][id] = q[k].dx; lds.ray[4][id] = q[k].dy; lds.ray[5][id] = q[k].dz;
+        if constexpr (Lds::kPrefilter) {
+            lds.rinv.v[0][id] = __builtin_amdgcn_rcpf(q[k].dx); lds.rinv.v[1][id] = __builtin_amdgcn_rcpf(q[k].dy); lds.rinv.v[2][id] = __builtin_amdgcn_rcpf(q[k].dz);
+        }
     }
     uint32_t n_pairs = 0;   // wave-uniform fill level of lds.pairs
     wave_sync();
@@ -1117,10 +1125,11 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 #endif
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    if (shift == 0u) m8 = box_children_kept<8>(q0, q1, q2, q3, r, t_best, a.bvh_err);
-                    else if (shift == 1u) m8 = box_children_kept<4>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
-                    else if (shift == 2u) m8 = box_children_kept<2>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
-                    else m8 = box_children_kept<1>(q0, q1, q2, q3, r, t_best, a.bvh_err, sub);
+                    const float ix = lds.rinv.v[0][src], iy = lds.rinv.v[1][src], iz = lds.rinv.v[2][src];
+                    if (shift == 0u) m8 = box_children_kept<8>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err);
+                    else if (shift == 1u) m8 = box_children_kept<4>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err, sub);
+                    else if (shift == 2u) m8 = box_children_kept<2>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err, sub);
+                    else m8 = box_children_kept<1>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err, sub);
                     m8 &= (2u << ((q0.w >> 8) & 7u)) - 1u;   // children that exist
                     leaf = ((q0.w >> 11) & 1u) != 0u;                       // BvhNode::meta
                     base = leaf ? (q0.w >> 12) * kFan : (q0.w >> 12);      // a leaf's first slot / an inner node's first child
