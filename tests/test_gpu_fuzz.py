@@ -110,7 +110,7 @@ def test_random_scene(tmp_path, seed, n_small, n_large, n_dup, few_emitters):
     ri, rt, nan_seen = o.closest_hits(org, dirs)
     bad = np.flatnonzero(((gi != ri) | (gt.view(np.uint32) != rt.view(np.uint32))) & ~nan_seen)
     assert bad.size == 0, f"{bad.size} rays differ, first {bad[:3]}: gpu {gi[bad[:3]]} oracle {ri[bad[:3]]}"
-    assert (ri >= 0).mean() > 0.4 and (ri < 0).sum() > 50
+    assert (ri >= 0).mean() > 0.4 and ((ri < 0).sum() > 50 or seed >= 100)     # (a soak scene may be closed on all sides: 3 misses in 60 000)
     # ties really occur and go to the lower index
     dup_hits = 0
     for k in np.flatnonzero(ri >= 0)[:5000]:
@@ -118,7 +118,7 @@ def test_random_scene(tmp_path, seed, n_small, n_large, n_dup, few_emitters):
         if len(same) > 1:
             dup_hits += 1
             assert ri[k] == same.min()
-    assert dup_hits > 0 or n_dup < 10      # (a soak configuration with a couple of duplicates among thousands need not hit one)
+    assert dup_hits > 0 or n_dup < 10 or 50 * n_dup < n     # (a soak configuration with a few duplicates among thousands need not hit one)
     # and a small frame through the integrator
     W, H, spp = 40, 28, 4
     s, s2, c, st = g.render_host(W, H, spp, 8)
