@@ -117,14 +117,19 @@ int pt_scene_create(const float *triangles, const int32_t *triangle_material, in
                     const float *materials, int32_t n_materials, int device, pt_scene **out);
 
 /* The same scene on another device (or host-only, device < 0): the parsed model, its tables and the culling hierarchies built
- * so far are SHARED with `scene` (reference-counted; either may be destroyed first), only the device copies are new.  A skybox
- * set before the call is inherited. */
+ * so far are SHARED with `scene` (reference-counted; either may be destroyed first), only the device copies are new.  The
+ * copy inherits the skybox `scene` has at the time of the call. */
 int pt_scene_clone_to_device(const pt_scene *scene, int device, pt_scene **out);
 
 /* -SKYBOX (config.h:26, scene.cpp:20-22): load a 24-bit BMP with bitmap_image::load_bitmap's checks
  * (bitmap_image.hpp:1508-1603) as the scene's skybox; rays that hit nothing then add its bilinear sample to the
- * accumulators (scene.cpp:126-154).  NULL or "" removes the skybox.  Not to be called while a render is in flight. */
+ * accumulators (scene.cpp:126-154).  NULL or "" removes the skybox.  Not to be called while a render is in flight.
+ * A skybox belongs to the HANDLE it is set on (the reference's Scene holds its own bitmap, scene.h:14): copies made from this
+ * handle afterwards (pt_scene_clone_to_device, pt_frame_create) inherit it, other copies of the same model keep theirs.  A
+ * failed call leaves the handle's skybox as it was. */
 int pt_scene_set_skybox_bmp(pt_scene *scene, const char *path);
+/* Width and height of the handle's skybox, 0 x 0 if it has none. */
+int pt_scene_skybox_size(const pt_scene *scene, int32_t *width, int32_t *height);
 
 int pt_scene_counts(const pt_scene *scene, int32_t *n_triangles, int32_t *n_materials);
 int pt_scene_get_triangles(const pt_scene *scene, float *triangles, int32_t *triangle_material);
@@ -190,6 +195,9 @@ int pt_frame_info(const pt_frame *frame, int32_t *n_bands, int32_t *band_rows, i
  * pass_begin / pass_count select the slice.  Returns without waiting unless stats != NULL (then: sums over the bands,
  * kernel_ms = the slowest band's). */
 int pt_frame_render(pt_frame *frame, const pt_render_params *params, pt_render_stats *stats);
+/* Diagnosis of a multi-device run: the kernel time of every band (ms[n_bands], HIP events on the band's stream) of the last
+ * pt_frame_render that asked for statistics, -1 where there is none.  stats->kernel_ms of that call is the slowest band's. */
+int pt_frame_band_kernel_ms(const pt_frame *frame, float *ms);
 int pt_frame_gather(pt_frame *frame);   /* enqueue the one collective of the frame; asynchronous */
 int pt_frame_wait(pt_frame *frame);     /* until everything enqueued so far -- kernels and gather -- is done */
 int pt_frame_read(pt_frame *frame, float *sum, float *sum2, int32_t *count);   /* gathers if a band changed since the last gather, waits, copies out */
@@ -257,10 +265,16 @@ int pt_scene_cull_tables(pt_scene *scene, float eps, int32_t *counts, float *clu
  * In pt_scene_cull_tables the cluster fields first_tri / n_tri are slot ranges. */
 int pt_scene_cull_layout(pt_scene *scene, float eps, int32_t *counts, int32_t *slot_triangle, void *bvh_nodes);
 
-/* The kernels' tables pack indices into bit fields: (ray, slot) work items hold a slot in 24 bits, a box-tree node its child
- * base in 21, a sphere tree has at most 8 levels.  A hierarchy beyond that is refused with PT_ERR_UNSUPPORTED when it is
- * built (first render with an eps, pt_scene_cull_tables / _layout), never truncated; this is the check itself, for counts. */
+/* The kernels' tables pack indices into bit fields: (ray, slot) work items hold a slot in 24 bits; a box-tree node keeps its
+ * base in 20 bits of BvhNode::meta (bits 12-31; bit 11 is the leaf flag) -- an inner node's first child, so fewer than 2^20
+ * nodes, or a leaf's first slot / 8 in the GLOBAL slot order, so with a box tree fewer than 2^23 slots --; a sphere tree has at
+ * most 8 levels; and the box tree, whose depth is variable, at most PT_MAX_BVH_DEPTH levels (the walk's stack slack is sized for
+ * that).  A hierarchy beyond any of these is refused with PT_ERR_UNSUPPORTED when it is built (first render with an eps,
+ * pt_scene_cull_tables / _layout), never truncated; this is the check itself, for counts.  bvh_depth = levels of the box tree
+ * (root = 1; 0 = no box tree). */
+#define PT_MAX_BVH_DEPTH 9
 int pt_table_limits_check(uint64_t n_slots, uint64_t n_bvh_nodes, int32_t n_levels);
+int pt_table_limits_check_tree(uint64_t n_slots, uint64_t n_bvh_nodes, int32_t n_levels, int32_t bvh_depth);
 
 /* Host seconds spent on this scene's model so far: seconds[0] = parsing + per-triangle tables (pt_scene_load_obj /
  * pt_scene_create), seconds[1] = building culling hierarchies (one per eps, shared by all per-device copies). */

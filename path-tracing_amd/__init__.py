@@ -35,7 +35,7 @@ ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_sc
                "pt_write_bmp", "pt_host_alloc", "pt_host_free", "pt_abi_version", "pt_device_count", "pt_last_error",
                "pt_scene_clone_to_device", "pt_scene_timings", "pt_table_limits_check", "pt_rccl_available",
                "pt_frame_create", "pt_frame_info", "pt_frame_render", "pt_frame_gather", "pt_frame_wait", "pt_frame_read",
-               "pt_frame_clear", "pt_frame_destroy"]
+               "pt_frame_clear", "pt_frame_destroy", "pt_frame_band_kernel_ms", "pt_scene_skybox_size", "pt_table_limits_check_tree"]
 FRAME_REHEARSE, FRAME_SELF_COLLECTIVE = 1, 2
 TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "device_copies"}
 
@@ -148,6 +148,9 @@ def load_library(path):
     L.pt_frame_clear.argtypes = [vp]
     L.pt_frame_destroy.argtypes = [vp]
     L.pt_frame_destroy.restype = None
+    L.pt_frame_band_kernel_ms.argtypes = [vp, fp]
+    L.pt_scene_skybox_size.argtypes = [vp, ip, ip]
+    L.pt_table_limits_check_tree.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]
     if hasattr(L, "pt_test_set_mutation"):
         L.pt_test_set_mutation.argtypes = [C.c_char_p, C.c_double]
     return L
@@ -247,6 +250,11 @@ class Scene:
         """-SKYBOX: a 24-bit BMP sampled by rays that hit nothing (scene.cpp:126-154); None or "" removes it."""
         _check(self._L.pt_scene_set_skybox_bmp(self._h, (path or "").encode()), self._L)
 
+    def skybox_size(self):
+        w, h = C.c_int32(), C.c_int32()
+        _check(self._L.pt_scene_skybox_size(self._h, C.byref(w), C.byref(h)), self._L)
+        return w.value, h.value
+
     def cull_tables(self, eps=1e-4):
         """The culling hierarchy for `eps` (diagnostics): dict of clusters, spheres, bary records, constants."""
         counts = np.zeros(4, np.int32)
@@ -270,7 +278,8 @@ class Scene:
         st = np.zeros(counts[0], np.int32)
         nodes = np.zeros((counts[1], 64), np.uint8)
         _check(self._L.pt_scene_cull_layout(self._h, eps, _ip(counts), _ip(st), nodes.ctypes.data_as(C.c_void_p)), self._L)
-        return {"slot_triangle": st, "bvh": nodes, "bvh_inner_nodes": int(counts[2]), "clusters": int(counts[3])}
+        return {"slot_triangle": st, "bvh": nodes, "bvh_inner_nodes": int(counts[2]), "clusters": int(counts[3]),
+                "bvh_depth": bvh_depth(nodes)}
 
     def trace_rays(self, origins, directions, eps=1e-4):
         """Closest hit per ray (scene.cpp:114-120).  directions must be unit length (normalised as ray.h:23 does)."""
@@ -338,6 +347,22 @@ class Session:
             pass
 
 
+def bvh_depth(nodes):
+    """Levels of a box tree from its 64-byte nodes (BvhNode::meta: children - 1 in bits 8-10, leaf flag bit 11, base in bits
+    12-31; children are consecutive nodes with larger indices): root = 1, no tree = 0."""
+    n = len(nodes)
+    if n == 0:
+        return 0
+    meta = np.ascontiguousarray(nodes).view(np.uint32).reshape(n, 16)[:, 3]
+    level = np.ones(n, np.int64)
+    for w in range(n):
+        m = int(meta[w])
+        if not (m >> 11) & 1:
+            base, k = m >> 12, ((m >> 8) & 7) + 1
+            level[base:base + k] = level[w] + 1
+    return int(level.max())
+
+
 class Frame:
     """pt_frame: one image on several devices from one host program -- row bands, one gather to the first device."""
 
@@ -360,6 +385,12 @@ class Frame:
         st = RenderStats()
         _check(self._L.pt_frame_render(self._h, C.byref(p), C.byref(st) if want_stats else None), self._L)
         return st.as_dict() if want_stats else None
+
+    def band_kernel_ms(self):
+        """Kernel time of every band of the last render(want_stats=True), -1 where there is none."""
+        ms = np.zeros(self.info()["bands"], np.float32)
+        _check(self._L.pt_frame_band_kernel_ms(self._h, _fp(ms)), self._L)
+        return ms.tolist()
 
     def gather(self):
         _check(self._L.pt_frame_gather(self._h), self._L)

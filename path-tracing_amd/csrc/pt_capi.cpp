@@ -57,11 +57,17 @@ namespace {
 // The layouts the kernels read pack indices into bit fields; a hierarchy that does not fit them must be refused, never
 // truncated: (ray, slot) pairs keep the slot in 24 bits (pt_kernels.hip: `e & 0xFFFFFF`), a box-tree node keeps its child
 // base in 20 bits (BvhNode::meta, `base << 12`: a child node, or a leaf's first slot / 8 -- fewer leaves than nodes; stack entries have 26), a sphere tree has at most kMaxLevels levels.
-int check_table_limits(unsigned long long n_slots, unsigned long long n_bvh_nodes, long long n_levels) {
+int check_table_limits(unsigned long long n_slots, unsigned long long n_bvh_nodes, long long n_levels, long long bvh_depth = 0) {
     if (n_slots >= (1ull << 24))
         return fail(PT_ERR_UNSUPPORTED, "the culling hierarchy has " + std::to_string(n_slots) + " slots; (ray, slot) work items hold 24 bits");
     if (n_bvh_nodes >= (1ull << 20))
         return fail(PT_ERR_UNSUPPORTED, "the box tree has " + std::to_string(n_bvh_nodes) + " nodes; a node's child base holds 20 bits");
+    // a leaf's base is its first slot / 8 in the global slot order: with a box tree the slots themselves must stay below 2^23
+    // (the builder puts the tree's slots first, so a leaf's base is below the node count anyway: this is the field's own bound)
+    if (n_bvh_nodes > 0 && n_slots >= (1ull << 23))
+        return fail(PT_ERR_UNSUPPORTED, "the culling hierarchy has " + std::to_string(n_slots) + " slots under a box tree; a leaf's base (first slot / 8) holds 20 bits");
+    if (bvh_depth > pt::kMaxBvhDepth)
+        return fail(PT_ERR_UNSUPPORTED, "the box tree has " + std::to_string(bvh_depth) + " levels; the walk's stack slack holds " + std::to_string(pt::kMaxBvhDepth));
     if (n_levels > pt::kMaxLevels)
         return fail(PT_ERR_UNSUPPORTED, "a sphere tree has " + std::to_string(n_levels) + " levels; the walk holds " + std::to_string(pt::kMaxLevels));
     return PT_OK;
@@ -86,8 +92,11 @@ int get_cull(pt_scene_host &h, float eps, std::shared_ptr<const pt::CullTables> 
     long long levels = 0;
     for (const auto &c : t->clusters)
         if (c.kind == 0) levels = std::max<long long>(levels, c.n_levels);
-    const int rc = check_table_limits(t->slot_tri.size(), t->bvh.size(), levels);
+    const int rc = check_table_limits(t->slot_tri.size(), t->bvh.size(), levels, t->bvh_depth);
     if (rc != PT_OK) return rc;
+    // the small-scene kernels' closest-hit key packs (original index, slot) into 16 bits each
+    if (!t->big && (t->slot_tri.size() >= 65536u || h.host.n_tri() >= 65536))
+        return fail(PT_ERR_UNSUPPORTED, "a scene on the sphere-tree path has " + std::to_string(t->slot_tri.size()) + " slots; its closest-hit key holds 16 bits");
     if (h.cull_cache.size() >= 4) h.cull_cache.erase(h.cull_cache.begin());
     h.cull_cache.push_back(t);
     out = t;
@@ -109,12 +118,12 @@ int upload(pt_scene *s, int device) {
     PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_mats), t.mats.size() * sizeof(pt::MatRec) + 64));
     if (!t.exact.empty()) PT_HIP_TRY(hipMemcpy(s->d_exact, t.exact.data(), t.exact.size() * sizeof(pt::ExactRec), hipMemcpyHostToDevice));
     if (!t.mats.empty()) PT_HIP_TRY(hipMemcpy(s->d_mats, t.mats.data(), t.mats.size() * sizeof(pt::MatRec), hipMemcpyHostToDevice));
-    const auto &sky = s->shared->sky;
-    if (!sky.empty()) {
+    if (s->sky && !s->sky->texels.empty()) {   // (a copy's skybox is the one of the handle it was made from)
+        const auto &sky = s->sky->texels;
         PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_sky), sky.size() + 64));
         PT_HIP_TRY(hipMemcpy(s->d_sky, sky.data(), sky.size(), hipMemcpyHostToDevice));
-        s->sky_w = s->shared->sky_w;
-        s->sky_h = s->shared->sky_h;
+        s->sky_w = s->sky->w;
+        s->sky_h = s->sky->h;
     }
     return PT_OK;
 }
@@ -215,6 +224,7 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.sky_h = scene->d_sky ? scene->sky_h : 0;
     a.n_clusters = static_cast<int32_t>(t.clusters.size());
     a.n_tri = scene->shared->host.n_tri();
+    a.big = t.big ? 1 : 0;
     a.n_slots = static_cast<uint32_t>(t.slot_tri.size());
     a.eps = eps;
     a.k1 = cc.k1; a.k2 = cc.k2; a.a_max = cc.a_max; a.m0 = cc.m0; a.m0_quad = cc.m0_quad; a.t_guard = cc.t_guard;
@@ -467,6 +477,17 @@ int pt_scene_timings(const pt_scene *scene, double *seconds) {
 int pt_table_limits_check(uint64_t n_slots, uint64_t n_bvh_nodes, int32_t n_levels) {
     return guarded([&] { return check_table_limits(n_slots, n_bvh_nodes, n_levels); });
 }
+int pt_table_limits_check_tree(uint64_t n_slots, uint64_t n_bvh_nodes, int32_t n_levels, int32_t bvh_depth) {
+    return guarded([&] { return check_table_limits(n_slots, n_bvh_nodes, n_levels, bvh_depth); });
+}
+static_assert(PT_MAX_BVH_DEPTH == pt::kMaxBvhDepth, "the ABI header states the box tree's depth limit");
+
+int pt_scene_skybox_size(const pt_scene *scene, int32_t *width, int32_t *height) {
+    if (!scene || !width || !height) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *width = scene->sky ? scene->sky->w : 0;
+    *height = scene->sky ? scene->sky->h : 0;
+    return PT_OK;
+}
 
 static int scene_load_obj_impl(const char *model_dir, const char *model_name, int device, pt_scene **out) {
     if (!model_dir || !model_name || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
@@ -477,7 +498,8 @@ static int scene_load_obj_impl(const char *model_dir, const char *model_name, in
     bool io = false;
     const auto t0 = std::chrono::steady_clock::now();
     if (!pt::load_obj(model_dir, model_name, s->shared->host, err, io)) return fail(io ? PT_ERR_IO : PT_ERR_PARSE, err);
-    pt_scene_host *h = s->shared.get();
+    // (finish_scene destroys the pt_scene on failure -- no device, bad ordinal, upload error --: keep the host side alive here)
+    const std::shared_ptr<pt_scene_host> h = s->shared;
     const int rc = finish_scene(std::move(s), device, out);
     h->load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();   // (includes the first device's upload)
     return rc;
@@ -502,7 +524,8 @@ static int scene_clone_impl(const pt_scene *src, int device, pt_scene **out) {
     if (!src || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     ScenePtr s(new pt_scene);
-    s->shared = src->shared;   // parsed model, tables, hierarchies built so far, skybox texels
+    s->shared = src->shared;   // parsed model, tables, hierarchies built so far
+    s->sky = src->sky;         // the skybox of the handle the copy is made from
     if (device >= 0) {
         const int rc = upload(s.get(), device);
         if (rc != PT_OK) return rc;
@@ -564,14 +587,17 @@ static int scene_set_skybox_bmp_impl(pt_scene *scene, const char *path) {
             PT_HIP_TRY(hipMemcpy(scene->d_sky, texels.data(), texels.size(), hipMemcpyHostToDevice));
         }
     }
-    // (per-device copies made from this scene AFTERWARDS inherit the skybox; copies made before keep what they had, with its size)
+    // (per-device copies made from THIS handle afterwards inherit the skybox; other handles of the same model keep theirs)
     scene->sky_w = w;
     scene->sky_h = h;
-    {
-        std::lock_guard<std::mutex> lock(scene->shared->cull_mutex);
-        scene->shared->sky.swap(texels);
-        scene->shared->sky_w = w;
-        scene->shared->sky_h = h;
+    if (texels.empty()) {
+        scene->sky.reset();
+    } else {
+        auto sk = std::make_shared<pt_sky_texels>();
+        sk->texels.swap(texels);
+        sk->w = w;
+        sk->h = h;
+        scene->sky = std::move(sk);
     }
     return PT_OK;
 }
@@ -1067,6 +1093,8 @@ int pt_test_set_mutation(const char *family, double value) {
     else if (f == "order_mode") m.order_mode = static_cast<int>(value);
     else if (f == "bvh_fill") m.bvh_fill = value;
     else if (f == "bvh_mode") m.bvh_mode = static_cast<int>(value);
+    else if (f == "bvh_depth_cap") m.bvh_depth_cap = static_cast<int>(value);
+    else if (f == "big_threshold") m.big_threshold = static_cast<int>(value);
     else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);
     else if (f == "tile_width") g_force_tile_width = static_cast<int>(value);
     else return fail(PT_ERR_INVALID_ARGUMENT, "unknown mutation family " + f);

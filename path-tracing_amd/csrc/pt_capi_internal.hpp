@@ -24,8 +24,13 @@ struct pt_scene_host {
     std::vector<std::shared_ptr<const pt::CullTables>> cull_cache;   // most recent last; a handful of eps values at most
     double load_seconds = 0;                                         // parsing + per-triangle tables
     double cull_build_seconds = 0;                                   // host time spent in build_cull_tables (pt_render -TIMING)
-    std::vector<uint8_t> sky;   // skybox texels (B,G,R; top-down rows; no padding), empty = none
-    int sky_w = 0, sky_h = 0;
+};
+
+// Skybox texels (B,G,R; top-down rows; no padding).  A skybox belongs to a pt_scene handle, not to the shared model: a per-device
+// copy inherits the one of the handle it was made FROM (the pointer is copied; texels are immutable once set).
+struct pt_sky_texels {
+    std::vector<uint8_t> texels;
+    int w = 0, h = 0;
 };
 
 // Device copy of one CullTables (they depend on eps; a scene keeps the one of the last eps it rendered with).
@@ -63,8 +68,9 @@ struct pt_scene {
     pt::ExactRec *d_exact = nullptr;
     pt::MatRec *d_mats = nullptr;
     int cu_count = 256;            // compute units of the scene's device
-    uint8_t *d_sky = nullptr;
-    int sky_w = 0, sky_h = 0;      // of the texels THIS copy has on its device (the shared host side may have moved on)
+    std::shared_ptr<const pt_sky_texels> sky;   // this handle's skybox (nullptr = none); copies made from it inherit it
+    uint8_t *d_sky = nullptr;      // the same texels on this copy's device
+    int sky_w = 0, sky_h = 0;
     // ensure_cull + the enqueue of a launch happen under launch_mutex (a concurrent render with another eps must not free
     // the tables in between); nothing waits for the device while holding it.
     std::mutex launch_mutex;

@@ -111,6 +111,7 @@ struct pt_frame {
     std::vector<ncclComm_t> comms;         // RCCL transport: one communicator per distinct device, rank = index
     hipStream_t gather_stream = nullptr;   // root device, RCCL transport only: the receives of the gather
     bool dirty = false;                    // a band was rendered or cleared since the last gather
+    std::vector<float> band_kernel_ms;     // per band: kernel time of the last pt_frame_render that asked for statistics (-1 = none yet)
     size_t n_px() const { return static_cast<size_t>(width) * height; }
     float *root_sum() const { return d_frame; }
     float *root_sum2() const { return d_frame + plane_floats; }
@@ -231,10 +232,12 @@ int frame_render_impl(pt_frame *f, const pt_render_params *p, pt_render_stats *s
     if (!stats) return PT_OK;
     std::memset(stats, 0, sizeof *stats);
     stats->kernel_ms = -1.0f;
+    f->band_kernel_ms.assign(nb, -1.0f);
     for (size_t b = 0; b < nb; ++b) {
         pt_render_stats bs;
         const int rc = ptc::session_collect(f->sessions[b], &bs);
         if (rc != PT_OK) return rc;
+        f->band_kernel_ms[b] = bs.kernel_ms;
         stats->samples_traced += bs.samples_traced; stats->segments += bs.segments; stats->contributing += bs.contributing;
         stats->exact_tests += bs.exact_tests; stats->misses += bs.misses; stats->wave_segments += bs.wave_segments;
         stats->wave_node_rounds += bs.wave_node_rounds; stats->wave_exact_iterations += bs.wave_exact_iterations;
@@ -249,8 +252,12 @@ int frame_render_impl(pt_frame *f, const pt_render_params *p, pt_render_stats *s
 
 int frame_gather_impl(pt_frame *f) {
     if (!f) return fail(PT_ERR_INVALID_ARGUMENT, "null frame");
-    f->dirty = false;
-    if (f->xfers.empty()) return PT_OK;
+    // (`dirty` is cleared only once the whole gather has been enqueued: after a failed one pt_frame_read tries again instead of
+    // handing out the root's stale rows)
+    if (f->xfers.empty()) {
+        f->dirty = false;
+        return PT_OK;
+    }
     if (f->transport == PT_FRAME_TRANSPORT_DEVICE_COPIES) {
         // rehearsal: the collective's transfers as plain copies, each on its band's stream (after that band's kernels)
         for (const FrameXfer &x : f->xfers) {
@@ -261,6 +268,7 @@ int frame_gather_impl(pt_frame *f) {
             else
                 PT_HIP_TRY(hipMemcpyPeerAsync(x.dst, f->devices[0], x.src, s->scene->device, x.words * 4, s->stream));
         }
+        f->dirty = false;
         return PT_OK;
     }
     // ONE group: every band's three planes, sent on the band's stream (so after its kernels) and received on the root's
@@ -278,6 +286,7 @@ int frame_gather_impl(pt_frame *f) {
     const ncclResult_t ge = r.GroupEnd();
     if (first_error != ncclSuccess) return rccl_fail(first_error, "ncclSend / ncclRecv");
     if (ge != ncclSuccess) return rccl_fail(ge, "ncclGroupEnd");
+    f->dirty = false;
     return PT_OK;
 }
 
@@ -349,6 +358,12 @@ int pt_frame_info(const pt_frame *f, int32_t *n_bands, int32_t *band_rows, int32
     return PT_OK;
 }
 
+int pt_frame_band_kernel_ms(const pt_frame *f, float *ms) {
+    if (!f || !ms) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    for (size_t b = 0; b < f->sessions.size(); ++b) ms[b] = b < f->band_kernel_ms.size() ? f->band_kernel_ms[b] : -1.0f;
+    return PT_OK;
+}
+
 int pt_frame_render(pt_frame *f, const pt_render_params *params, pt_render_stats *stats) {
     return guarded([&] { return frame_render_impl(f, params, stats); });
 }
@@ -371,6 +386,12 @@ int pt_frame_clear(pt_frame *f) {
 
 void pt_frame_destroy(pt_frame *f) {
     if (!f) return;
+    // a gather may still be in flight: its sends sit on the bands' streams, its receives on the root's gather stream -- both are
+    // drained before the communicators go
+    if (f->gather_stream && !f->devices.empty()) {
+        (void)hipSetDevice(f->devices[0]);
+        (void)hipStreamSynchronize(f->gather_stream);
+    }
     for (pt_session *s : f->sessions) pt_session_destroy(s);   // waits for the band's stream
     if (!f->comms.empty()) {
         Rccl &r = rccl();

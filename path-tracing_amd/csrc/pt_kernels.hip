@@ -566,11 +566,11 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
         return __any(x);
     };
     constexpr uint32_t kNodeStack = Lds::kNodeStack, kPairQueue = Lds::kPairQueue;
-    // Small scenes (at most kBigSceneTriangles = 2048 triangles, so 16 bits each): the closest-hit key carries the SLOT
+    // Small scenes (CullTables::big == false: at most kSmallSceneMaxTriangles triangles and slots, so 16 bits each): the closest-hit key carries the SLOT
     // below the original index, and shading reads the slot-ordered record the exact test has just pulled through the
     // caches.  Big scenes look the hit up in the table kept in the original order.
     constexpr bool kPackSlot = !Lds::kPrefilter;
-    static_assert(kBigSceneTriangles < 65536, "packed (original index, slot) key");
+    static_assert(kSmallSceneMaxTriangles < 32768, "packed (original index, slot) key: 16 bits each, slots padded to at most twice the triangles");
     ++st.w_segments;
     PT_STAMP(st, 0);   // everything since the last stamp: ray generation / loop control
 #pragma unroll
@@ -1896,7 +1896,7 @@ hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, con
                              int32_t *d_hit_index, float *d_hit_t, hipStream_t stream) {
     if (n_rays <= 0) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((n_rays + kBlock - 1) / kBlock);
-    if (args.n_tri > kBigSceneTriangles)
+    if ((args.big != 0))
         hipLaunchKernelGGL(trace_rays_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, args, d_origins, d_directions, n_rays, d_hit_index, d_hit_t);
     else
         hipLaunchKernelGGL(trace_rays_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, args, d_origins, d_directions, n_rays, d_hit_index, d_hit_t);
@@ -1941,7 +1941,7 @@ hipError_t launch_integrator(const RenderArgs &args0, hipStream_t stream) {
     args.blockprof = d_cnt;
     char name[128];
     std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dELb0ELb0EEEvNS_10RenderArgsE", args.sky ? 1 : 0,
-                  args.n_tri > kBigSceneTriangles ? 1 : 0, args.stats ? 1 : 0, args.may_leave_envelope ? 1 : 0);
+                  (args.big != 0) ? 1 : 0, args.stats ? 1 : 0, args.may_leave_envelope ? 1 : 0);
     hipFunction_t f;
     e = hipModuleGetFunction(&f, mod, name);
     if (e != hipSuccess) return e;
@@ -1967,7 +1967,7 @@ hipError_t integrator_waves_per_cu(const RenderArgs &, int *waves) {
     return hipSuccess;
 }
 void integrator_plan_tiles(RenderArgs &args, int, int) {   // (the instrumented code object holds the wide variant only)
-    const int rays = (!args.sky && !args.stats) ? (args.n_tri > kBigSceneTriangles ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
+    const int rays = (!args.sky && !args.stats) ? ((args.big != 0) ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
     args.narrow = 0;
     args.blocks_x = (args.width + kTileW * rays - 1) / (kTileW * rays);
     args.n_tiles = static_cast<uint32_t>(args.blocks_x) * static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
@@ -1989,7 +1989,7 @@ bool launch_with_stats(const RenderArgs &args) {
 // Calls f(kernel) with the instantiation a launch with these arguments runs.
 template <class F>
 void with_instantiation(const RenderArgs &args, F &&f) {
-    const bool big = args.n_tri > kBigSceneTriangles;
+    const bool big = (args.big != 0);
     const bool stats = launch_with_stats(args);
     auto pick = [&](auto sky, auto bg, auto st) {
         constexpr bool S = decltype(sky)::value, B = decltype(bg)::value, T = decltype(st)::value;
@@ -2039,7 +2039,7 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
 // statistics-free small-scene kernel owns 16 x 8 tiles (two pixels per lane) -- unless that would leave the chip's wave slots
 // underfilled, in which case its 8 x 8 variant runs (a tile's passes are a serial chain: fewer tiles than slots means idle SIMDs).
 void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
-    const bool sky = args.sky != nullptr, big = args.n_tri > kBigSceneTriangles, stats = launch_with_stats(args);
+    const bool sky = args.sky != nullptr, big = (args.big != 0), stats = launch_with_stats(args);
     const uint32_t rows = static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
     int rays = (!sky && !stats) ? (big ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
     args.narrow = 0;

@@ -29,6 +29,7 @@ struct RenderArgs {
     int32_t *count;
     unsigned long long *stats;   // 24 counters (11 used; 16.. = phase timers of diagnostic builds) or nullptr
     int32_t n_clusters, n_tri;
+    int32_t big;                 // CullTables::big: the hierarchy is the box tree (big-scene instantiations), not sphere trees
     uint32_t n_slots;            // slots of the hierarchy (>= n_tri: the box tree pads its leaves)
     int32_t width, height, row_begin, row_end;
     int32_t pass_begin, pass_count, mrr;

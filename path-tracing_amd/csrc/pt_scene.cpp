@@ -599,7 +599,10 @@ void quantise_node(BvhNode &q, const Box &nb, const std::vector<Box> &kids, bool
             q.lo[x][c] = static_cast<uint8_t>(std::max(0.0, std::min(255.0, lo)));
             q.hi[x][c] = static_cast<uint8_t>(std::max(0.0, std::min(255.0, hi)));
         }
-    q.meta = static_cast<uint32_t>(e + 127) | (static_cast<uint32_t>(k - 1) << 8) | (leaf ? 1u << 11 : 0u) | (base << 12);
+    // (base: an inner node's first child or a leaf's ordinal -- the tree's slots are the FIRST slots of the global order, so a
+    // leaf's first slot / 8 is its ordinal among the leaves --: below the node count either way, which check_table_limits bounds
+    // by 2^20 before any table reaches a device; a tree beyond that is still built, with the field wrapped, and then refused)
+    q.meta = static_cast<uint32_t>(e + 127) | (static_cast<uint32_t>(k - 1) << 8) | (leaf ? 1u << 11 : 0u) | ((base & 0xFFFFFu) << 12);
 }
 
 // Box tree of a big scene over the (non-degenerate, small) triangles `ids`: uniform depth, up to 8 children per node,
@@ -609,6 +612,7 @@ void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::ve
                double eps_line, CullTables &out, std::vector<int> &order) {
     out.bvh.clear();
     out.bvh_inner = 0;
+    out.bvh_depth = 0;
     out.bvh_err = static_cast<float>(5.0e-7 * PT_MUT(box_err));   // first-order worst case 3.6e-7 (tests/test_cull_margins_host.py)
     const size_t n = ids.size();
     if (n == 0) return;
@@ -658,6 +662,7 @@ void build_bvh(const HostScene &s, const std::vector<TriGeo> &geo, const std::ve
     size_t total = 0;
     for (int L = top; L >= 1; --L) { level_first[L] = total; total += levels[L].size(); }
     out.bvh_inner = static_cast<uint32_t>(level_first[1]);
+    out.bvh_depth = static_cast<uint32_t>(top);
     out.bvh.resize(total);
     std::vector<Box> node_box(total, kEmptyBox);
     std::vector<std::vector<Box>> kid_box(total);
@@ -707,6 +712,7 @@ void build_bvh_sah(const HostScene &s, const std::vector<TriGeo> &geo, const std
                    double eps_line, CullTables &out, std::vector<int> &order) {
     out.bvh.clear();
     out.bvh_inner = 0;
+    out.bvh_depth = 0;
     out.bvh_err = static_cast<float>(5.0e-7 * PT_MUT(box_err));
     const size_t n = ids.size();
     if (n == 0) return;
@@ -831,6 +837,17 @@ void build_bvh_sah(const HostScene &s, const std::vector<TriGeo> &geo, const std
         for (int k : kids) wide_bin.push_back(k);   // (children of w: consecutive node indices, in this order)
     }
     const size_t total = wide_bin.size();
+    {   // levels of the wide tree: nodes are in breadth-first order, so a node's level is its parent's + 1 in one forward pass
+        std::vector<uint32_t> level(total, 1);
+        uint32_t next = 1, deepest = 1;
+        for (size_t w = 0; w < total; ++w)
+            for (size_t c = 0; c < wide_kids[w].size(); ++c) {
+                level[next] = level[w] + 1;
+                deepest = std::max(deepest, level[next]);
+                ++next;
+            }
+        out.bvh_depth = deepest;
+    }
     // a node's first child: nodes are appended in the order of their parents
     std::vector<uint32_t> first_child(total, 0);
     {
@@ -877,6 +894,13 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     const double eps = eps_f;
     out = CullTables();
     out.eps = eps_f;
+    // sphere trees + small-scene kernels, or one box tree + big-scene kernels (pt_scene.hpp: kBigSceneTriangles)
+    int big_threshold = kBigSceneTriangles;
+#ifdef PT_TEST_HOOKS
+    if (g_cull_mutation.big_threshold >= 0) big_threshold = std::min(g_cull_mutation.big_threshold, kSmallSceneMaxTriangles);
+#endif
+    const bool big = T > big_threshold;
+    out.big = big;
 
     // ---- scene-wide bounds
     double r_max = 20.0;   // the camera origin (0,0,-20), main.cpp:129
@@ -938,7 +962,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
     }
     // A big scene's few emitters (the light of a room) join the large class whatever their size: their records alone then
     // tell which rays of a path's last segment can still contribute (pt_kernels.hip, "last segment").
-    if (T > kBigSceneTriangles) {
+    if (big) {
         auto emits = [&](int t) {
             const float *m = &s.mat[10 * static_cast<size_t>(s.tri_mat[t])];
             return m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f;
@@ -994,7 +1018,7 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
 #endif
     bool any_large = false;
     for (int i = 0; i < T; ++i) any_large |= large[i] != 0;
-    if (absorb && any_large && T <= kBigSceneTriangles) {
+    if (absorb && any_large && !big) {
         for (auto &g : groups) {
             // ... unless they are so small that their barycentric gradients (1 / height) would blow up the margin of
             // the whole class: the test of every large triangle uses the class-wide a_max
@@ -1006,7 +1030,6 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
         }
         groups.erase(std::remove_if(groups.begin(), groups.end(), [](const std::vector<int> &g) { return g.empty(); }), groups.end());
     }
-    const bool big = T > kBigSceneTriangles;
     // Can a path leave the envelope (origins within r_org) the margins are derived for?  Only through a hit point outside
     // it, i.e. only if some triangle's acceptance region reaches beyond it: a near-degenerate triangle (the reference
     // accepts it for points anywhere along its axis) or a long sliver at the edge of the scene.  Scenes without such
@@ -1031,6 +1054,17 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
 #endif
         if (mode == 1) build_bvh_sah(s, geo, cen, ids, eps_line, out, order);
         else build_bvh(s, geo, cen, ids, eps_line, out, order);
+        // The SAH tree's depth follows the geometry (nested shells of geometrically growing triangles: 12 levels for 12 000
+        // triangles) and the walk's stack slack bounds it (kMaxBvhDepth): such a scene gets the uniform-depth tree instead.
+#ifdef PT_TEST_HOOKS
+        const uint32_t depth_cap = static_cast<uint32_t>(g_cull_mutation.bvh_depth_cap);
+#else
+        const uint32_t depth_cap = static_cast<uint32_t>(kMaxBvhDepth);
+#endif
+        if (mode == 1 && out.bvh_depth > depth_cap) {
+            order.clear();
+            build_bvh(s, geo, cen, ids, eps_line, out, order);
+        }
     } else if (!groups.empty()) {
         if (static_cast<int>(groups.size()) > kMaxClusters) {   // a cloud of loose triangles: one tree over all of them
             std::vector<int> all;

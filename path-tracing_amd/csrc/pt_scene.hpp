@@ -60,7 +60,19 @@ static const int kMaxLevels = 8; // small class: tree levels per cluster (8^8 tr
 #define PT_TILE_W 8
 #endif
 static const int kTileW = PT_TILE_W, kTileH = 64 / PT_TILE_W;
-static const int kBigSceneTriangles = 2048;   // above this the kernel walks one box tree over all small triangles, with deep queues
+// The box tree's depth is variable (build_bvh_sah).  The kernel's walk commits the top item of a full node stack whatever
+// its children need (pt_kernels.hip, "Rare: not everything fits"): in that mode the stack holds a depth-first path, at most 7
+// waiting siblings per inner level above kNodeStack, and the stack has 64 entries of slack: 7 x (depth - 1) <= 64 allows 10
+// levels; 9 are allowed (same value as PT_MAX_BVH_DEPTH of the ABI header).  A deeper SAH tree is replaced by the uniform-depth
+// tree (build_bvh: at most 8 levels below 2^24 triangles).
+static const int kMaxBvhDepth = 9;
+// Above kBigSceneTriangles triangles a scene gets ONE box tree over all its small triangles and the big-scene kernels (deep
+// queues, pair pre-filter); up to it, sphere trees per connected group and the small-scene kernels.  The switch is made by the
+// table builder (CullTables::big) -- the kernels and launchers only read the flag -- at the crossover measured on the MI355X
+// (profiles/r04_t_sweep.jsonl).  The small-scene kernels pack (original index, slot) into 16 bits each: never beyond
+// kSmallSceneMaxTriangles whatever a test hook asks for.
+static const int kBigSceneTriangles = 2048;
+static const int kSmallSceneMaxTriangles = 16384;
 static const int kMaxClusters = 8;            // small scenes: more connected groups than this are merged into one cluster
 
 // SLOT ORDER.  The culling hierarchy does not follow the file order of the triangles: the table builder groups them
@@ -121,6 +133,8 @@ struct CullTables {
     std::vector<ClusterDesc> clusters;
     std::vector<BvhNode> bvh;        // big scenes only: box tree over the small triangles (slots [0, 8 * leaves))
     uint32_t bvh_inner = 0;          // inner nodes of the box tree (the other nodes are leaves: 8 slots each)
+    uint32_t bvh_depth = 0;          // levels of the box tree (root = 1, 0 = no tree); at most kMaxBvhDepth
+    bool big = false;                // the scene takes the box-tree path (big-scene kernels)
     float bvh_err = 0;               // relative rounding allowance of the kernel's slab arithmetic
     CullConstants cc;
     float eps = 0;
@@ -142,6 +156,8 @@ struct CullMutation {
     int emis_drop = 0;                // table builder: 1 = the lowest emitter bit of the large class is cleared (a WRONG table: negative control)
     int no_last_segment_filter = 0;   // integrator: 1 = a path's last segment searches all triangles like every other segment
     double bvh_fill = 0.5;    // box tree: target fill of a node's children (builder tuning; uniform-depth builder)
+    int bvh_depth_cap = kMaxBvhDepth;   // SAH trees deeper than this are replaced by the uniform-depth tree (tests raise it to see the refusal)
+    int big_threshold = -1;   // triangles above which a scene takes the box-tree path: -1 = the library's (kBigSceneTriangles)
     int bvh_mode = -1;        // box tree builder: -1 = the library's default, 0 = uniform depth, 1 = binary SAH collapsed to 8-wide nodes
     int order_mode = 0;   // small-scene clusters: 0 = cheaper of (cells, patches), 1 = as filed, 2 = cells, 3 = patches
 };

@@ -139,10 +139,18 @@ def test_table_limits_are_refused_not_truncated(tmp_path):
     """The kernels pack a slot into 24 bits of a (ray, slot) pair and a box-tree node's child base into 20 bits of
     BvhNode::meta; a hierarchy beyond either must be refused (synthetic counts: no 16 M-triangle scene needed)."""
     L = pt.lib()
-    assert L.pt_table_limits_check((1 << 24) - 1, (1 << 20) - 1, 8) == pt.PT_OK
+    assert L.pt_table_limits_check((1 << 24) - 1, 0, 8) == pt.PT_OK
+    assert L.pt_table_limits_check((1 << 23) - 1, (1 << 20) - 1, 8) == pt.PT_OK
     assert L.pt_table_limits_check(1 << 24, 10, 3) == 7 and b"24 bits" in L.pt_last_error()          # PT_ERR_UNSUPPORTED
     assert L.pt_table_limits_check(1000, 1 << 20, 3) == 7 and b"20 bits" in L.pt_last_error()
     assert L.pt_table_limits_check(1000, 10, 9) == 7 and b"levels" in L.pt_last_error()
+    # a leaf's base is its first slot / 8 in the same 20 bits: with a box tree the slots stay below 2^23
+    assert L.pt_table_limits_check((1 << 23) - 1, 1000, 3) == pt.PT_OK
+    assert L.pt_table_limits_check(1 << 23, 1000, 3) == 7 and b"first slot / 8" in L.pt_last_error()
+    assert L.pt_table_limits_check(1 << 23, 0, 3) == pt.PT_OK                       # (no box tree: only the 24 bits of a pair)
+    # the box tree's depth is variable and the walk's stack slack bounds it (pt_hip.h: PT_MAX_BVH_DEPTH)
+    assert L.pt_table_limits_check_tree(1000, 100, 3, 9) == pt.PT_OK
+    assert L.pt_table_limits_check_tree(1000, 100, 3, 10) == 7 and b"levels" in L.pt_last_error() and b"stack slack" in L.pt_last_error()
     # what the builder produces for a scene of the size class the advisor worried about stays far inside: slots per triangle
     # and nodes per triangle of the biggest scene of the suite
     import sys
@@ -153,8 +161,52 @@ def test_table_limits_are_refused_not_truncated(tmp_path):
     s = pt.Scene.load_obj(d, "x64.obj", device=-1)
     lay = s.cull_layout()
     n_tri = s.counts()[0]
-    assert len(lay["slot_triangle"]) < 4 * n_tri and len(lay["bvh"]) < n_tri      # so 2^21 nodes are beyond the 2^23-triangle bound's reach only
+    assert len(lay["slot_triangle"]) < 4 * n_tri and len(lay["bvh"]) < n_tri      # so 2^20 nodes are beyond the 2^23-triangle bound's reach only
                                                                                     # for trees the check above refuses
+    assert 1 <= lay["bvh_depth"] <= 9
+    # the tree's slots are the FIRST slots (a leaf's base = its ordinal among the leaves < node count): every leaf's base x 8
+    # names slots of the tree, the large class follows
+    meta = lay["bvh"].view(np.uint32).reshape(-1, 16)[:, 3]
+    leaves = meta[(meta >> 11) & 1 == 1]
+    assert len(leaves) == len(lay["bvh"]) - lay["bvh_inner_nodes"]
+    assert sorted((leaves >> 12).tolist()) == list(range(len(leaves)))
+
+
+def test_box_tree_depth_is_bounded(tmp_path):
+    """A SAH tree deeper than the walk's stack slack allows is replaced by the uniform-depth tree over the same triangles (the
+    test hook lowers the bound so that an ordinary scene trips it), and the header's constant is the builder's."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_nested_scene as N
+    d = str(tmp_path) + "/"
+    N.generate(os.path.join(ROOT, "models"), d, "Nested.obj", 6000)
+    H = pt.load_library(os.path.join(os.path.dirname(pt.LIB_PATH), "libpt_testhooks.so"))
+    try:
+        H.pt_test_set_mutation(b"reset", 0.0)
+        sah = pt.Scene.load_obj(d, "Nested.obj", device=-1, library=H).cull_layout()
+        H.pt_test_set_mutation(b"bvh_depth_cap", 4.0)
+        uni = pt.Scene.load_obj(d, "Nested.obj", device=-1, library=H).cull_layout()
+    finally:
+        H.pt_test_set_mutation(b"reset", 0.0)
+    assert sah["bvh_depth"] >= 6 and uni["bvh_depth"] == 5          # 8^5 >= 6 014 > 8^4
+    live = lambda lay: sorted(t for t in lay["slot_triangle"].tolist() if t >= 0)
+    assert live(sah) == live(uni) == list(range(6014))
+    assert 'define PT_MAX_BVH_DEPTH 9' in open(os.path.join(ROOT, "include", "pt_hip.h")).read()
+
+
+def test_a_skybox_belongs_to_the_handle_it_is_set_on(models_dir, tmp_path):
+    path = str(tmp_path / "sky.bmp")
+    O.write_bmp(path, np.random.default_rng(1).integers(0, 256, (5, 7, 3)).astype(np.uint8))
+    s = pt.Scene.load_obj(models_dir, "Tor.obj", device=-1)
+    before = s.clone_to_device(-1)
+    s.set_skybox(path)
+    after = s.clone_to_device(-1)
+    after.set_skybox(None)                       # clearing a copy's skybox leaves the source's alone ...
+    again = s.clone_to_device(-1)                # ... so a copy made from the source now still gets one
+    assert s.skybox_size() == (7, 5) and before.skybox_size() == (0, 0) and after.skybox_size() == (0, 0) and again.skybox_size() == (7, 5)
+    with pytest.raises(pt.PtError):
+        s.set_skybox(str(tmp_path / "missing.bmp"))
+    assert s.skybox_size() == (7, 5)
 
 
 def test_rccl_loads_and_exports_what_the_gather_calls():

@@ -131,3 +131,32 @@ def test_smallest_queues_find_every_hit(models_dir, tmp_path):
     assert st["partial_commit_rounds"] > 100000
     g = pt.Scene.load_obj(d, name, device=0)
     assert _digest(*g.render_host(960, 540, 2, 8, error=-1.0, want_stats=False)[:3]) == _digest(s, s2, c)
+
+
+def test_smallest_queues_on_a_deep_tree_of_nested_triangles(tmp_path):
+    """The box tree's depth follows the geometry (build_bvh_sah), and a node stack that is full commits its top item whatever the
+    children need: the stack then holds a depth-first path, up to 7 siblings per level beyond its nominal size -- what the 64
+    entries of slack and the depth bound (kMaxBvhDepth) are for.  Nested, geometrically growing triangles on the camera axis
+    (tools/make_nested_scene.py) give a tree deeper than any other scene of the suite, rays through the centre keep most
+    children of every node, and the smallest legal stack (libpt_verify_tiny.so: 64 entries) forces commit after commit: every
+    segment is compared with the all-triangles loop, for the SAH tree and for the uniform-depth tree a deeper scene falls back to."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_nested_scene as N
+    d = str(tmp_path) + "/"
+    N.generate(os.path.join(ROOT, "models"), d, "Nested.obj", 12000)
+    L = pt.load_library(os.path.join(os.path.dirname(pt.VERIFY_LIB_PATH), "libpt_verify_tiny.so"))
+    g = pt.Scene.load_obj(d, "Nested.obj", device=0)
+    shipped = _digest(*g.render_host(480, 270, 4, 8, error=-1.0, want_stats=False)[:3])
+    for cap, deep in ((9, True), (4, False)):
+        L.pt_test_set_mutation(b"reset", 0.0)
+        L.pt_test_set_mutation(b"bvh_depth_cap", float(cap))
+        try:
+            v = pt.Scene.load_obj(d, "Nested.obj", device=0, library=L)
+            depth = v.cull_layout()["bvh_depth"]
+            assert (depth >= 7) if deep else (depth == 5), depth          # 12 014 triangles: 8^5 holds them in the uniform tree
+            s, s2, c, st = v.render_host(480, 270, 4, 8, error=-1.0)
+        finally:
+            L.pt_test_set_mutation(b"reset", 0.0)
+        assert st["verify_checked"] == st["segments"] > 480 * 270 * 4 and st["verify_mismatches"] == 0, (cap, st)
+        assert st["partial_commit_rounds"] > 10000, st
+        assert _digest(s, s2, c) == shipped, cap

@@ -46,3 +46,27 @@ def test_c_api_host_side_is_clean_under_tsan(tmp_path, models_dir):
     assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
     assert "WARNING: ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
     assert "resolve ok" in run.stdout and "hierarchy threads bad 0" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"), reason="g++ or the HIP headers are not available")
+def test_c_api_error_paths_are_clean_under_asan(tmp_path, models_dir):
+    """Every loader's failure path destroys the half-built scene inside the call (no device, ordinal out of range): nothing may
+    touch it afterwards (round 3's pt_scene_load_obj wrote its timing into the freed host side).  The C API's host code under
+    AddressSanitizer + UBSan, kernel launchers stubbed; runs with or without a GPU (the bad ordinal is 9999)."""
+    import numpy as np
+    import oracle_lib as O
+    exe = str(tmp_path / "capi_asan")
+    csrc = os.path.join(ROOT, "path-tracing_amd", "csrc")
+    build = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                            "-D__HIP_PLATFORM_AMD__", "-I", csrc, "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                            os.path.join(ROOT, "tests", "native", "capi_asan_main.cpp"), os.path.join(csrc, "pt_capi.cpp"),
+                            os.path.join(csrc, "pt_frame.cpp"), os.path.join(csrc, "pt_scene.cpp"), "-o", exe,
+                            "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    sky = str(tmp_path / "sky.bmp")
+    O.write_bmp(sky, np.random.default_rng(2).integers(0, 256, (6, 9, 3)).astype(np.uint8))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")      # (the HIP runtime's own start-up allocations are not ours to judge)
+    run = subprocess.run([exe, models_dir, sky], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+    assert "capi error paths ok" in run.stdout
