@@ -37,6 +37,7 @@ ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_sc
                "pt_frame_create", "pt_frame_info", "pt_frame_render", "pt_frame_gather", "pt_frame_wait", "pt_frame_read",
                "pt_frame_clear", "pt_frame_destroy", "pt_frame_band_kernel_ms", "pt_scene_skybox_size", "pt_table_limits_check_tree"]
 FRAME_REHEARSE, FRAME_SELF_COLLECTIVE = 1, 2
+BIG_SCENE_TRIANGLES = 1024     # csrc/pt_scene.hpp: kBigSceneTriangles -- scenes above it take the box-tree path (tests/test_abi_host.py compares)
 TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "device_copies"}
 
 

@@ -69,9 +69,11 @@ static const int kMaxBvhDepth = 9;
 // Above kBigSceneTriangles triangles a scene gets ONE box tree over all its small triangles and the big-scene kernels (deep
 // queues, pair pre-filter); up to it, sphere trees per connected group and the small-scene kernels.  The switch is made by the
 // table builder (CullTables::big) -- the kernels and launchers only read the flag -- at the crossover measured on the MI355X
-// (profiles/r04_t_sweep.jsonl).  The small-scene kernels pack (original index, slot) into 16 bits each: never beyond
+// (profiles/r04_t_sweep.jsonl: the torus 1 ... 32 times in the room through either path; 526 triangles: sphere trees 5 000
+// against 3 910 Msamples/s, 1 038: 3 550 / 3 500, 1 550: 2 840 / 3 340, 2 062: 2 380 / 3 120 -- the constant was 2 048 until
+// round 4, a 20 % step at the switch).  The small-scene kernels pack (original index, slot) into 16 bits each: never beyond
 // kSmallSceneMaxTriangles whatever a test hook asks for.
-static const int kBigSceneTriangles = 2048;
+static const int kBigSceneTriangles = 1024;
 static const int kSmallSceneMaxTriangles = 16384;
 static const int kMaxClusters = 8;            // small scenes: more connected groups than this are merged into one cluster
 

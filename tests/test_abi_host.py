@@ -172,6 +172,20 @@ def test_table_limits_are_refused_not_truncated(tmp_path):
     assert sorted((leaves >> 12).tolist()) == list(range(len(leaves)))
 
 
+def test_the_small_big_switch_is_where_the_header_says(tmp_path):
+    import re
+    import sys
+    hdr = open(os.path.join(ROOT, "path-tracing_amd", "csrc", "pt_scene.hpp")).read()
+    assert int(re.search(r"kBigSceneTriangles = (\d+);", hdr).group(1)) == pt.BIG_SCENE_TRIANGLES
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_replicated_scene as M
+    d = str(tmp_path) + "/"
+    for inst, tree in ((3, False), (4, True)):
+        n = M.generate(os.path.join(ROOT, "models"), d, f"x{inst}.obj", inst)
+        lay = pt.Scene.load_obj(d, f"x{inst}.obj", device=-1).cull_layout()
+        assert (n > pt.BIG_SCENE_TRIANGLES) == tree == (len(lay["bvh"]) > 0), (inst, n)
+
+
 def test_box_tree_depth_is_bounded(tmp_path):
     """A SAH tree deeper than the walk's stack slack allows is replaced by the uniform-depth tree over the same triangles (the
     test hook lowers the bound so that an ordinary scene trips it), and the header's constant is the builder's."""

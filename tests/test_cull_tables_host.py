@@ -243,7 +243,7 @@ def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path, bvh_mode, request)
     import make_replicated_scene as M
     d = str(tmp_path) + "/"
     n_tri = M.generate(os.path.join(ROOT, "models"), d, "x9.obj", 9)
-    assert n_tri > 2048
+    assert n_tri > pt.BIG_SCENE_TRIANGLES
     hooks = pt.load_library(pt.TESTHOOKS_LIB_PATH)
     hooks.pt_test_set_mutation(b"reset", 0.0)
     hooks.pt_test_set_mutation(b"bvh_mode", float(bvh_mode))     # (the test-hook build rebuilds the hierarchy at every call:

@@ -128,7 +128,7 @@ def test_all_instantiations_match_the_oracle(tmp_path, models_dir, sky, big):
     d = str(tmp_path) + "/"
     if big:
         d, name, n = _replica(tmp_path, 9)            # 9 x 256 + 14 = 2318 triangles: above the deep-queue threshold
-        assert n > 2048
+        assert n > pt.BIG_SCENE_TRIANGLES
     else:
         name = "Tor.obj"
         for f in ("Tor.obj", "Tor.mtl"):
@@ -158,3 +158,35 @@ def test_all_instantiations_match_the_oracle(tmp_path, models_dir, sky, big):
             if want_stats:
                 assert st["segments"] == rst["segments"] and st["misses"] == rst["misses"]
                 assert st["n_triangles"] == o.n_tri
+
+
+# ---- both sides of the switch between the sphere-tree path and the box-tree path (pt_scene.hpp: kBigSceneTriangles) ------
+@pytest.mark.parametrize("instances", [3, 4], ids=["x3_782_triangles", "x4_1038_triangles"])
+def test_both_sides_of_the_small_big_switch_match_the_oracle(tmp_path, instances):
+    """The torus 3 times in the room (782 triangles: sphere trees, small-scene kernels) and 4 times (1 038: one box tree,
+    big-scene kernels) -- the neighbours of the switch, moved from 2 048 to 1 024 triangles in round 4 (profiles/r04_t_sweep.jsonl)
+    -- through the shipped library, and each of them forced through the OTHER path by the test hook: the oracle's bits every time."""
+    d, name, n = _replica(tmp_path, instances)
+    assert (n > pt.BIG_SCENE_TRIANGLES) == (instances == 4)
+    o = O.Scene.load(d, name)
+    W, H, spp, mrr = 64, 40, 12, 8
+    H_ = pt.load_library(os.path.join(os.path.dirname(pt.LIB_PATH), "libpt_testhooks.so"))
+    for err in (-1.0, 0.01):
+        rs, rs2, rc, rst = O.render(o, W, H, spp, mrr, error=err)
+        for lib, thr in ((None, None), (H_, 0.0), (H_, 16384.0)):
+            if thr is not None:
+                lib.pt_test_set_mutation(b"reset", 0.0)
+                lib.pt_test_set_mutation(b"big_threshold", thr)
+            try:
+                g = pt.Scene.load_obj(d, name, device=0, library=lib)
+                has_tree = len(g.cull_layout()["bvh"]) > 0
+                assert has_tree == ((n > pt.BIG_SCENE_TRIANGLES) if thr is None else (thr == 0.0))
+                for want_stats in (True, False):
+                    s, s2, c, st = g.render_host(W, H, spp, mrr, error=err, want_stats=want_stats)
+                    assert np.array_equal(c, rc), (instances, thr, want_stats, err)
+                    assert np.array_equal(_bits(s), _bits(rs)) and np.array_equal(_bits(s2), _bits(rs2)), (instances, thr, want_stats, err)
+                    if want_stats:
+                        assert st["segments"] == rst["segments"] and st["misses"] == rst["misses"]
+            finally:
+                if thr is not None:
+                    lib.pt_test_set_mutation(b"reset", 0.0)

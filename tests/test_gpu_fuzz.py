@@ -93,7 +93,7 @@ def test_random_scene(tmp_path, seed, n_small, n_large, n_dup, few_emitters):
     assert g.counts()[0] == o.n_tri == n
     rng = np.random.default_rng(seed + 100)
     tri, tri_mat = o.triangles()
-    if few_emitters and n > 2048:      # the box-tree kernel's last-segment test is on: every emitter sits in the large class
+    if few_emitters and n > pt.BIG_SCENE_TRIANGLES:      # the box-tree kernel's last-segment test is on: every emitter sits in the large class
         emitters = set(np.flatnonzero((o.materials()[tri_mat, 3:6] != 0).any(1)).tolist())
         lay = g.cull_layout()
         large = set(int(t) for t in lay["slot_triangle"][(len(lay["bvh"]) - lay["bvh_inner_nodes"]) * 8:] if t >= 0)

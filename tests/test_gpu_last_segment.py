@@ -30,7 +30,7 @@ def _scene_dir(tmp_path, models_dir, torus_emits, light_emits, replicas=0):
     if replicas:
         sys.path.insert(0, os.path.join(os.path.dirname(models_dir), "tools"))
         import make_replicated_scene as M
-        assert M.generate(models_dir, d, "Tor.obj", replicas) > 2048      # the box-tree kernel
+        assert M.generate(models_dir, d, "Tor.obj", replicas) > pt.BIG_SCENE_TRIANGLES      # the box-tree kernel
     else:
         shutil.copy(os.path.join(models_dir, "Tor.obj"), d + "Tor.obj")
     out, cur = [], None

@@ -376,9 +376,10 @@ def test_compacted_adaptive_passes_on_scenes_with_several_trees(tmp_path, hooks_
     assert rst["samples_traced"] < 0.8 * W * H * spp        # the adaptive skip really bites (about 60 % of the pixels end up skipping)
     for width_mode in (2.0, 1.0):
         hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
+        hooks_lib.pt_test_set_mutation(b"big_threshold", 16384.0)      # (1 550 triangles are beyond the shipped switch: keep the sphere trees)
         try:
             h = pt.Scene.load_obj(d, "r.obj", device=0, library=hooks_lib)
-            assert h.counts()[0] == o.n_tri <= 2048
+            assert h.counts()[0] == o.n_tri and len(h.cull_layout()["bvh"]) == 0
             s, s2, c, _ = h.render_host(W, H, spp, 8, want_stats=False, **kw)
         finally:
             hooks_lib.pt_test_set_mutation(b"reset", 0.0)
