@@ -34,6 +34,12 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   cxx_frame     the same frame(s) driven by the C++ host alone (pt_render -GPUS N: pt_frame_*, direct RCCL), as a child process
   configs1_64spp / adaptive_default / configs4_replica   (N = 1) BASELINE configs[1], the reference-default -ERR 0.001 run
                 with its traced-sample count, and configs[4] (the x64 / x195 replicated scenes) with its own counters
+  configs2_1024spp   (N = 1) BASELINE configs[2], the "rocprof HBM GB/s run": Tor.obj 1080p x 1024 spp, with FETCH_SIZE / WRITE_SIZE
+                of that launch from live --pmc passes at 1024 spp
+  skybox_open   (N = 1) an OPEN scene under a sky bitmap (Tor.obj without its back wall, tools/make_open_scene.py): the skybox
+                instantiation with path regeneration; rate, live rays per wave-segment, segments per sample, bit identity with
+                the oracle on a band
+  multi_gpu_diagnosis   (N > 1) every rank's own kernel time and one gather timed alone after all kernels are done
 """
 import argparse
 import datetime
@@ -65,6 +71,7 @@ PEAK_VALU_TLANEOPS = 78.6432    # the same without FMA: one operation per lane p
 PEAK_HBM_GBS = 8000.0
 BASE_W, BASE_H, SPP, MRR = 1920, 1080, 256, 8
 C3_W, C3_H, C3_SPP = 3840, 2160, 256      # BASELINE configs[3]
+C2_SPP = 1024                             # BASELINE configs[2]
 KERNEL_SOURCES = ["pt_kernels.hip", "pt_kernels.hpp", "pt_fastfp.hpp", "pt_scene.cpp", "pt_scene.hpp", "pt_capi.cpp"]
 EXE = os.path.join(ROOT, "path-tracing_amd", "bin", "pt_render")
 MODELS = os.path.join(ROOT, "models") + "/"
@@ -174,7 +181,7 @@ PMC_PASSES_TOR = [PMC_SQ, ["FETCH_SIZE"], ["WRITE_SIZE"]]
 PMC_PASSES_BIG = [PMC_SQ, ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"]]
 
 
-def pmc_live(passes, model_dir, model_name, spp, big, deadline):
+def pmc_live(passes, model_dir, model_name, spp, big, deadline, sky=None):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
@@ -191,6 +198,8 @@ def pmc_live(passes, model_dir, model_name, spp, big, deadline):
             cmd = [exe, "--pmc", *group, "-d", d, "-o", "p", "--output-format", "csv", "--", EXE, "--W", str(BASE_W), "--H", str(BASE_H),
                    "-RPP", str(spp), "-MRR", str(MRR), "-ERR", "-1", "-SEED", "42", "-MODEL_PATH", model_dir, "-MODEL_NAME", model_name,
                    "-BENCH_STEPS", "1", "-BENCH_WARMUP", "1"]
+            if sky:
+                cmd += ["-SKYBOX", sky]
             r = run_group(cmd, left, cwd=td, env=dict(os.environ, TMPDIR=td))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -198,7 +207,7 @@ def pmc_live(passes, model_dir, model_name, spp, big, deadline):
             rows = []
             for x in csv.DictReader(open(max(files, key=os.path.getmtime))):
                 inst = instantiation(x["Kernel_Name"])
-                if inst and not inst[2] and inst[1] == big:      # the statistics-free instantiation of this scene class
+                if inst and not inst[2] and inst[1] == big and inst[0] == bool(sky):      # the statistics-free instantiation of this scene class
                     rows.append(x)
             launches = len({x["Dispatch_Id"] for x in rows})
             if not launches:
@@ -321,16 +330,31 @@ def reference_stream_accuracy(models, pt, scene):
         a = scene.render_host(W, H, passes, int(f["mrr"]), error=-1.0, seed=int(seed), want_stats=False)
         s += a[0]; s2 += a[1]; c += a[2]
     r = R.compare((f["sum"], f["sum2"], f["count"]), (s.astype(np.float32), s2.astype(np.float32), c.astype(np.int32)))
+    gpu = (s.astype(np.float32), s2.astype(np.float32), c.astype(np.int32))
+    binned = {b: R.compare_blocks((f["sum"], f["sum2"], f["count"]), gpu, W, H, b) for b in sorted(R.TOLERANCE["blocks"])}
     ok = True
     try:
         R.assert_same_image(r)
+        for rb in binned.values():
+            R.assert_same_binned_image(rb)
     except AssertionError:
         ok = False
-    return {"vs": "oracle with ORC_RNG_SEQUENTIAL + libm trig (the reference's minstd_rand0 streams), 128x128, seeds 42..49 x 512 passes",
-            "rmse_rgb_float_image": [ch["rmse_image"] for ch in r["channels"]],
-            "rmse_predicted_from_variance": [ch["rmse_image_predicted"] for ch in r["channels"]],
-            "z_rms": [ch["z_rms"] for ch in r["channels"]], "z_mean": [ch["z_mean"] for ch in r["channels"]],
-            "tolerance": R.TOLERANCE, "within_tolerance": ok}
+    seeds = [int(x) for x in f["seeds"]]
+    out = {"vs": f"oracle with ORC_RNG_SEQUENTIAL + libm trig (the reference's minstd_rand0 streams), {W}x{H}, seeds {seeds[0]}..{seeds[-1]} x {passes} passes "
+                 f"= {len(seeds) * passes} samples per pixel",
+           "rmse_rgb_float_image": [ch["rmse_image"] for ch in r["channels"]],
+           "rmse_predicted_from_variance": [ch["rmse_image_predicted"] for ch in r["channels"]],
+           "z_rms": [ch["z_rms"] for ch in r["channels"]], "z_mean": [ch["z_mean"] for ch in r["channels"]],
+           "tolerance": R.TOLERANCE, "within_tolerance": ok}
+    # the stated per-channel image tolerance: the resolved float image binned 8 x 8 (and 16 x 16) pixels, RMSE in units of 1/255
+    for b, rb in binned.items():
+        out[f"binned_{b}x{b}"] = {"rmse_rgb_float_image": [ch["rmse_image"] for ch in rb["channels"]],
+                                  "rmse_predicted_from_variance": [ch["rmse_image_predicted"] for ch in rb["channels"]],
+                                  "max_abs_diff_float_image": [ch["max_abs_diff_image"] for ch in rb["channels"]],
+                                  "z_rms": [ch["z_rms"] for ch in rb["channels"]], "bins": [ch["n"] for ch in rb["channels"]],
+                                  "tolerance_rmse": R.TOLERANCE["blocks"][b]["rmse_image_max"]}
+    out["brightness_z"] = [ch["brightness_z"] for ch in binned[min(binned)]["channels"]]
+    return out
 
 
 def cxx_frame_leg(n_bands, W, H, spp, steps, warmup, rehearse, error=-1.0, model_dir=MODELS, model_name="Tor.obj"):
@@ -393,12 +417,20 @@ def main():
             name = f"TorX{inst}.obj"
             replicas.append((inst, name, M.generate(os.path.join(ROOT, "models"), replica_dir + "/", name, inst)))
 
+        # the open scene of the skybox leg: Tor.obj without its back wall + a generated sky bitmap
+        import make_open_scene
+        make_open_scene.generate(os.path.join(ROOT, "models"), replica_dir)
+
     pmc, pmc_source, pmc_big, pmc_big_source = None, "not collected", None, "not collected"
+    pmc_c2, pmc_c2_source, pmc_sky, pmc_sky_source = None, "not collected", None, "not collected"
     if world == 1 and args.pmc == "live":      # child processes; this process has not touched the GPU yet
-        deadline = time.perf_counter() + 120
+        deadline = time.perf_counter() + 150
         pmc, pmc_source = pmc_live(PMC_PASSES_TOR, MODELS, "Tor.obj", args.spp, False, deadline)
         if extra:
             pmc_big, pmc_big_source = pmc_live(PMC_PASSES_BIG, replica_dir + "/", replicas[0][1], SPP, True, deadline)
+            # BASELINE configs[2] is "the rocprof HBM GB/s run": its own FETCH_SIZE / WRITE_SIZE, at 1024 spp
+            pmc_c2, pmc_c2_source = pmc_live([["FETCH_SIZE"], ["WRITE_SIZE"]], MODELS, "Tor.obj", C2_SPP, False, deadline)
+            pmc_sky, pmc_sky_source = pmc_live([PMC_SQ], replica_dir + "/", "TorOpen.obj", SPP, False, deadline, sky=os.path.join(replica_dir, "sky.bmp"))
 
     import numpy as np
     import torch
@@ -426,6 +458,8 @@ def main():
     scene = pt.Scene.load_obj(MODELS, "Tor.obj", device=local)
     n_tri = scene.counts()[0]
     stream = torch.cuda.current_stream(dev)
+
+    diagnosis = []      # N > 1: one entry per run_frames call
 
     def run_frames(sc, W, H, spp, steps, warmup, error=-1.0):
         """Renders `warmup` untimed and `steps` timed frames of a W x H x spp image cut into `world` row bands; returns
@@ -494,6 +528,21 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+            # diagnosis (untimed): every rank's mean kernel time, and ONE gather alone -- all kernels are done, nothing overlaps it
+            mine = torch.tensor([sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=rdev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            k = (frame_no[0] - 1) % n_band
+            send = band_bufs[k].cpu() if args.rehearse_on_one_gpu else band_bufs[k]
+            fence()
+            tg = time.perf_counter()
+            recv_bufs[k], work = bands.gather_bands(send, W, H, dist, rank, world, out=recv_bufs[k], async_op=True)
+            in_flight[0] = (work, k, send)
+            fence()
+            diagnosis.append({"frame": f"{W}x{H} x {spp} spp", "kernel_ms_per_rank": [float(x.item()) for x in every],
+                              "gather_alone_ms": (time.perf_counter() - tg) * 1e3, "ms_per_step": elapsed / steps * 1e3,
+                              "what": "kernel_ms_per_rank = HIP events around each rank's launches (mean over the timed steps); gather_alone_ms = one "
+                                      "gather of the bands to rank 0 with every kernel already done (host clock, barrier to barrier)"})
         frame = gathered[0] if world > 1 else [band_bufs[0]]
         return elapsed, kernel_ms, frame_stats, frame, rows
 
@@ -553,6 +602,56 @@ def main():
             rep[f"x{inst}"] = r
             big_scene.close()
         legs["configs4_replica"] = rep
+
+        # BASELINE configs[2]: Tor.obj 1080p x 1024 spp, "the rocprof HBM GB/s run" -- driver-timed, with the HBM bytes of THAT launch
+        c2, c2_st = leg(scene, BASE_W, BASE_H, C2_SPP, 3, f"BASELINE configs[2]: Tor.obj {BASE_W}x{BASE_H} x {C2_SPP} spp, -MRR {MRR}, -ERR -1")
+        c2_algo = BASE_W * BASE_H * 28 * 2 + n_tri * 56
+        c2_traffic = (pmc_c2["FETCH_SIZE"] + pmc_c2["WRITE_SIZE"]) * 1024.0 if pmc_c2 and "FETCH_SIZE" in pmc_c2 and "WRITE_SIZE" in pmc_c2 else None
+        c2["hbm"] = {"algorithmic_bytes": c2_algo, "traffic_bytes": c2_traffic,
+                     "traffic_over_algorithmic": c2_traffic / c2_algo if c2_traffic else None,
+                     "chunks_per_tile": int(c2_st.get("n_chunks", 0)) or None,
+                     "achieved": (c2_traffic or c2_algo) / (c2["kernel_ms"] * 1e-3) / 1e9 if c2["kernel_ms"] > 0 else None,
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": ((c2_traffic or c2_algo) / (c2["kernel_ms"] * 1e-3) / 1e9) / PEAK_HBM_GBS if c2["kernel_ms"] > 0 else None,
+                     "counters_source": pmc_c2_source,
+                     "fetch_kib": pmc_c2.get("FETCH_SIZE") if pmc_c2 else None, "write_kib": pmc_c2.get("WRITE_SIZE") if pmc_c2 else None}
+        if args.save_pmc and pmc_c2:
+            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false,false,false>", "width": BASE_W, "height": BASE_H, "spp": C2_SPP, "mrr": MRR,
+                       "kernel_source_sha": kernel_source_sha(), "kernel_ms": c2["kernel_ms"], "counters_per_launch": pmc_c2,
+                       "hbm": c2["hbm"], "collected_by": "bench.py --save-pmc (configs2_1024spp): " + pmc_c2_source,
+                       "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes over pt_render on the 1024-spp frame"},
+                      open(re.sub(r"(_pmc_hbm)?\.json$", "", args.save_pmc) + "_c2_pmc_hbm.json", "w"), indent=1)
+        legs["configs2_1024spp"] = c2
+        # Row N1 of the round-3 review: an OPEN scene under a sky.  Most paths end on their first or second segment; the skybox
+        # instantiation regenerates paths (a lane whose path has ended starts its pixel's next pass at once).
+        open_scene = pt.Scene.load_obj(replica_dir + "/", "TorOpen.obj", device=local)
+        open_scene.set_skybox(os.path.join(replica_dir, "sky.bmp"))
+        sk, sk_st = leg(open_scene, BASE_W, BASE_H, SPP, 5, f"Tor.obj without its back wall (266 triangles) under a 256x128 sky bitmap, {BASE_W}x{BASE_H} x {SPP} spp, "
+                        f"-MRR {MRR}, -ERR -1: integrate_kernel<true,false,...> with path regeneration")
+        n_samples = float(BASE_W * BASE_H * SPP)
+        sk["segments_per_sample"] = sk_st["segments"] / n_samples
+        sk["misses_per_sample"] = sk_st["misses"] / n_samples
+        sk["contributing_per_sample"] = sk_st["contributing"] / n_samples
+        sk["live_rays_per_wave_segment"] = sk_st["segments"] / float(sk_st["wave_segments"]) if sk_st["wave_segments"] else None
+        sk["live_rays_per_wave_segment_of"] = 64
+        sk["without_regeneration"] = {"live_rays_per_wave_segment": 32.7, "value": 5297.0, "spp": 64,
+                                      "source": "profiles/r04_open_scene_probe_before.jsonl (the same scene and kernel before regeneration, another box)"}
+        v = valu_view(pmc_sky, sk["kernel_ms"], float(sk_st["segments"]))
+        sk["roofline"] = {"bound": "valu_issue", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s", **v, "kernel_ms": sk["kernel_ms"],
+                          "kernel": "pt::integrate_kernel<true,false,false,false,false,false>", "counters_source": pmc_sky_source,
+                          "issue": issue_view(pmc_sky, sk["kernel_ms"], float(sk_st["wave_segments"]) or None)}
+        if args.cpu_seconds > 0:      # parity of THIS leg: a band of the same frame against the oracle, bit for bit
+            import oracle_lib as O
+            osc = O.Scene.load(replica_dir + "/", "TorOpen.obj")
+            osc.set_skybox(os.path.join(replica_dir, "sky.bmp"))
+            r0 = BASE_H // 2 - 8
+            cs, cs2, cc, cst = O.render(osc, BASE_W, BASE_H, 8, MRR, rows=(r0, r0 + 16), threads=min(O.lib().orc_max_threads(), host_cores()))
+            gs, gs2, gc, _ = open_scene.render_host(BASE_W, BASE_H, 8, MRR, rows=(r0, r0 + 16), want_stats=False)
+            sk["accumulators_bit_identical_to_oracle"] = bool(np.array_equal(gs.view(np.uint32), cs.view(np.uint32)) and
+                                                              np.array_equal(gs2.view(np.uint32), cs2.view(np.uint32)) and np.array_equal(gc, cc))
+            sk["oracle_sample"] = f"rows {r0}-{r0 + 16} x 8 spp, {cst['segments']} segments, {cst['misses']} misses"
+        legs["skybox_open"] = sk
+        open_scene.close()
 
     # the C++ host alone on the same frame(s): N = 1 must agree with `value`; for N > 1 it is the direct-RCCL frame path
     cxx = None
@@ -641,6 +740,8 @@ def main():
         }
         if rccl_ranks_seen is not None:
             out["rccl_ranks_seen"] = rccl_ranks_seen
+        if diagnosis:
+            out["multi_gpu_diagnosis"] = diagnosis
         if c3 is not None:
             out["configs3_strong"] = c3
         out.update(legs)

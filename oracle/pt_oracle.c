@@ -581,6 +581,40 @@ static inline void ray_reflect(orc_ray *r, const float *begin, const float *dir,
     r->depth++;
 }
 
+/* The skybox lookup of Scene::TraceRay's miss branch (scene.cpp:126-149): direction -> (r, g, b) / 256 of the bilinear
+ * sample, with the weights as written there. */
+static void sky_sample(const orc_scene *sc, const float *d, int trig_policy, float *out) {
+    const float pi = 3.141593f;
+    float ac, at;
+    if (trig_policy == ORC_TRIG_LIBM) { ac = acosf(d[1]); at = atan2f(d[2], -d[0]); }
+    else { ac = portable_acosf(d[1]); at = portable_atan2f(d[2], -d[0]); }
+    const float theta = ac / pi;
+    const float phi = at / pi / 2 + 0.5f;
+    const float x = phi * (float)(unsigned)sc->sky_w, y = theta * (float)(unsigned)sc->sky_h;
+    /* static_cast<unsigned>(float): undefined for NaN / out of range in the reference; here such values,
+     * and a coordinate that lands on the last row/column + 1, are clamped into the image */
+    unsigned x1 = (x >= 0.0f) ? (x < 4294967040.0f ? (unsigned)x : 0xFFFFFFFFu) : 0u;
+    unsigned y1 = (y >= 0.0f) ? (y < 4294967040.0f ? (unsigned)y : 0xFFFFFFFFu) : 0u;
+    if (x1 > (unsigned)sc->sky_w - 1u) x1 = (unsigned)sc->sky_w - 1u;
+    if (y1 > (unsigned)sc->sky_h - 1u) y1 = (unsigned)sc->sky_h - 1u;
+    const unsigned x2 = (x1 + 1) % (unsigned)sc->sky_w, y2 = (y1 + 1) % (unsigned)sc->sky_h;
+    const unsigned char *t1 = sc->sky + ((size_t)y1 * sc->sky_w + x1) * 3, *t2 = sc->sky + ((size_t)y1 * sc->sky_w + x2) * 3;
+    const unsigned char *t3 = sc->sky + ((size_t)y2 * sc->sky_w + x1) * 3, *t4 = sc->sky + ((size_t)y2 * sc->sky_w + x2) * 3;
+    const float ax = 1 - x + (float)x1, ay = 1 - y + (float)y1;   /* the weights of scene.cpp:146-149, as written */
+    for (int k = 0; k < 3; ++k) {                                   /* k: r,g,b = bytes 2,1,0 */
+        const float c1 = (float)t1[2 - k], c2 = (float)t2[2 - k], c3 = (float)t3[2 - k], c4 = (float)t4[2 - k];
+        const float c12 = c1 * (1.0f - ax) + c2 * ax;             /* glm::mix(x, y, a) = x*(1-a) + y*a */
+        const float c34 = c3 * (1.0f - ax) + c4 * ax;
+        out[k] = (c12 * (1.0f - ay) + c34 * ay) / 256.f;
+    }
+}
+/* the same for caller-supplied directions (tests: tests/test_double_entry.py); returns 0, or -1 without a skybox */
+int orc_probe_skybox(const orc_scene *sc, int n, const float *dirs, int trig_policy, float *rgb) {
+    if (!sc->sky) return -1;
+    for (int i = 0; i < n; ++i) sky_sample(sc, dirs + 3 * i, trig_policy, rgb + 3 * i);
+    return 0;
+}
+
 /* Scene::TraceRay (scene.cpp:113-157, no-skybox branch) + Material::Process (material.h:36-50)
  * + the three lobes (material.h:67-102). */
 static void trace_segment(orc_ctx *cx, orc_ray *r) {
@@ -598,30 +632,9 @@ static void trace_segment(orc_ctx *cx, orc_ray *r) {
     if (cur < 0) {                                                          /* scene.cpp:125-156 */
         cx->st->misses++;
         if (sc->sky) {
-            const float pi = 3.141593f;
-            float ac, at;
-            if (cx->pr->trig_policy == ORC_TRIG_LIBM) { ac = acosf(r->d[1]); at = atan2f(r->d[2], -r->d[0]); }
-            else { ac = portable_acosf(r->d[1]); at = portable_atan2f(r->d[2], -r->d[0]); }
-            const float theta = ac / pi;
-            const float phi = at / pi / 2 + 0.5f;
-            const float x = phi * (float)(unsigned)sc->sky_w, y = theta * (float)(unsigned)sc->sky_h;
-            /* static_cast<unsigned>(float): undefined for NaN / out of range in the reference; here such values,
-             * and a coordinate that lands on the last row/column + 1, are clamped into the image */
-            unsigned x1 = (x >= 0.0f) ? (x < 4294967040.0f ? (unsigned)x : 0xFFFFFFFFu) : 0u;
-            unsigned y1 = (y >= 0.0f) ? (y < 4294967040.0f ? (unsigned)y : 0xFFFFFFFFu) : 0u;
-            if (x1 > (unsigned)sc->sky_w - 1u) x1 = (unsigned)sc->sky_w - 1u;
-            if (y1 > (unsigned)sc->sky_h - 1u) y1 = (unsigned)sc->sky_h - 1u;
-            const unsigned x2 = (x1 + 1) % (unsigned)sc->sky_w, y2 = (y1 + 1) % (unsigned)sc->sky_h;
-            const unsigned char *t1 = sc->sky + ((size_t)y1 * sc->sky_w + x1) * 3, *t2 = sc->sky + ((size_t)y1 * sc->sky_w + x2) * 3;
-            const unsigned char *t3 = sc->sky + ((size_t)y2 * sc->sky_w + x1) * 3, *t4 = sc->sky + ((size_t)y2 * sc->sky_w + x2) * 3;
-            const float ax = 1 - x + (float)x1, ay = 1 - y + (float)y1;   /* the weights of scene.cpp:146-149, as written */
-            for (int k = 0; k < 3; ++k) {                                   /* k: r,g,b = bytes 2,1,0 */
-                const float c1 = (float)t1[2 - k], c2 = (float)t2[2 - k], c3 = (float)t3[2 - k], c4 = (float)t4[2 - k];
-                const float c12 = c1 * (1.0f - ax) + c2 * ax;             /* glm::mix(x, y, a) = x*(1-a) + y*a */
-                const float c34 = c3 * (1.0f - ax) + c4 * ax;
-                const float c = (c12 * (1.0f - ay) + c34 * ay) / 256.f;
-                cx->sum[k] += c; cx->sum2[k] += c * c;
-            }
+            float c3[3];
+            sky_sample(sc, r->d, cx->pr->trig_policy, c3);
+            for (int k = 0; k < 3; ++k) { cx->sum[k] += c3[k]; cx->sum2[k] += c3[k] * c3[k]; }
             ++*cx->count;
             cx->st->contributing++;
         }

@@ -16,6 +16,7 @@
 #ifdef PT_TEST_HOOKS
 static int g_items_per_slot = 0;
 static int g_force_tile_width = 0;   // 1 = always 8 x 8 tiles, 2 = always the widest the instantiation has, 0 = by tile count
+static int g_regen_min_dead = 0;     // test build: overrides RenderArgs::regen_min_dead (0 = the library's)
 #endif
 
 namespace ptc {
@@ -233,6 +234,10 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
     a.last_segment_filter = 1;
 #ifdef PT_TEST_HOOKS
     if (pt::g_cull_mutation.no_last_segment_filter) a.last_segment_filter = 0;
+#endif
+    a.regen_min_dead = pt::kRegenMinDead;
+#ifdef PT_TEST_HOOKS
+    if (g_regen_min_dead > 0) a.regen_min_dead = static_cast<uint32_t>(g_regen_min_dead);
 #endif
     a.emis_clusters = t.emis_clusters;
     a.emis_large_w0 = t.emis_large_w0;
@@ -1079,7 +1084,8 @@ int pt_test_set_mutation(const char *family, double value) {
     if (!family) return PT_ERR_INVALID_ARGUMENT;
     const std::string f = family;
     pt::CullMutation &m = pt::g_cull_mutation;
-    if (f == "reset") { m = pt::CullMutation(); g_items_per_slot = 0; g_force_tile_width = 0; }
+    if (f == "reset") { m = pt::CullMutation(); g_items_per_slot = 0; g_force_tile_width = 0; g_regen_min_dead = 0; }
+    else if (f == "regen_min_dead") g_regen_min_dead = static_cast<int>(value);
     else if (f == "sphere_r2") m.sphere_r2 = value;
     else if (f == "m0") m.m0 = value;
     else if (f == "k12") m.k12 = value;

@@ -1256,6 +1256,16 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
     static_assert(!NARROW || (!SKY && !STATS), "only the statistics-free, skybox-free kernels have a narrow variant");
     constexpr int R = NARROW ? 1 : rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
     static_assert(!ADAPT || (R == 2 && !BIG), "compaction moves a lane's second pixel into another lane's free first slot");
+    // REGEN = path regeneration: a lane whose path has ended starts its pixel's NEXT pass at once instead of idling until the
+    // longest path of the wave is done.  The skybox instantiations run this way: a scene with a skybox is an open scene, most
+    // paths end on their first or second segment (scene.cpp:125-155: a miss ends the path) -- Tor.obj without its back wall has
+    // 32.7 of 64 rays alive per wave-segment at -MRR 8 (profiles/r04_open_scene_probe_before.jsonl), the closed room 63.6.  The
+    // frame cannot change: a pixel's passes still run in order on its own lane (its contributions are added in pass order, its
+    // adaptive-sampling answer is the one main.cpp:118-125 computes before that pass), and the RNG counter is (pixel, pass,
+    // segment) whatever the other lanes are doing.  The closed-room kernels keep the pass loop: there regeneration gains
+    // nothing and would cost the last-segment filter, which needs the wave's rays to reach their last segment together.
+    constexpr bool REGEN = SKY;
+    static_assert(!REGEN || !ADAPT, "the compacting instantiation keeps the pass loop");
     constexpr int kTW = kTileW * R;
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R, ADAPT> lds;   // one wave per workgroup: all wave-private
 
@@ -1428,7 +1438,24 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
         return __any(v);
     };
 
-    for (int pass = pass_first; pass < pass_last; ++pass) {
+    // this lane's path state (REGEN: across passes -- a lane is in a pass of its own)
+    Ray q[R];
+    float tr[R], tg[R], tb[R];   // Ray::color_ (throughput), ray.h:17
+    int depth[R];
+    int cur_pass[R], next_pass[R];   // REGEN: the pass slot k's path belongs to / the next one its pixel has no ray for yet
+    float spare[R][3];               // REGEN: primary direction made in advance for pass spare_pass[k], if have_spare[k]
+    int spare_pass[R];
+    bool have_spare[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        tr[k] = tg[k] = tb[k] = 1.0f;
+        depth[k] = mrr;
+        cur_pass[k] = next_pass[k] = spare_pass[k] = pass_first;
+        have_spare[k] = false;
+        spare[k][0] = spare[k][1] = 0.0f; spare[k][2] = 1.0f;
+        q[k].ox = q[k].oy = q[k].oz = 0.0f; q[k].dx = q[k].dy = 0.0f; q[k].dz = 1.0f;
+    }
+    for (int pass = pass_first; REGEN ? pass == pass_first : pass < pass_last; ++pass) {   // (REGEN: one trip, the loop inside runs all passes)
         // Adaptive skip, main.cpp:118-125.
         bool skip[R], traced[R];
         if constexpr (ADAPT) {
@@ -1439,9 +1466,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             skip[k] = !in_image[k] || (pass > 10 && (pass % 4) && lowvar[k]);
+            if constexpr (REGEN) skip[k] = true;   // (paths are started inside the segment loop)
             traced[k] = !skip[k];
         }
-        if (!any_of(traced)) continue;
+        if constexpr (!REGEN) {
+            if (!any_of(traced)) continue;
+        }
         // Compaction (ADAPT).  With adaptive sampling on, most pixels of a tile sit out most passes of the second half of a
         // frame (Tor.obj, -ERR 0.001, 256 spp: 46 of a tile's 128 pixels are still traced at the end), scattered over the tile:
         // a wave with two pixels per lane would run nearly every pass at full cost for a third of the rays.  So a pass in which
@@ -1486,16 +1516,10 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
         const bool k1_on = two;   // (PT_SLOT_ON)
 
         // Primary ray, main.cpp:126-129 + Ray ctor ray.h:21-25 (double arithmetic, then narrowed).
-        Ray q[R];
-        float tr[R], tg[R], tb[R];   // Ray::color_ (throughput), ray.h:17
-        int depth[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            tr[k] = tg[k] = tb[k] = 1.0f;
-            depth[k] = mrr;
-            if (PT_SLOT_ON(k) && !skip[k]) {
+        auto primary_dir = [&](int k, int pass_k, float &out_dx, float &out_dy, float &out_dz) {
+            {
                 uint32_t w0, w1, w2, w3;
-                philox4x32_10(rng_pixel(k), static_cast<uint32_t>(pass), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
+                philox4x32_10(rng_pixel(k), static_cast<uint32_t>(pass_k), 0xFFFFFFFFu, 0u, a.seed, kPhiloxKey1, w0, w1, w2, w3);
                 const double jx = jitter_double(w0), jy = jitter_double(w1);
                 // x, y are made opaque once per pass so that their int->double conversions (and the doubles of width and
                 // height) are redone here instead of being hoisted out of the pass loop, where they would occupy eight
@@ -1516,23 +1540,109 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
                 }
                 int wi = a.width, hi = a.height;
                 asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
-                q[k].dx = static_cast<float>((xi + jx) / wi - 0.5f);
-                q[k].dy = static_cast<float>(-(yi + jy) / hi + 0.5f);
-                q[k].dz = 1.0f;
-                const float inv = rcp_rn_normal(sqrt_rn_normal((q[k].dx * q[k].dx + q[k].dy * q[k].dy) + (1.0f * 1.0f + 0.0f * 0.0f)));   // 1 <= argument < 2
-                q[k].dx = q[k].dx * inv; q[k].dy = q[k].dy * inv; q[k].dz = q[k].dz * inv;
-                q[k].ox = 0.0f; q[k].oy = 0.0f; q[k].oz = -20.0f;
-                depth[k] = 0;
-            } else {
-                q[k].ox = q[k].oy = q[k].oz = 0.0f; q[k].dx = q[k].dy = 0.0f; q[k].dz = 1.0f;
+                const float ddx = static_cast<float>((xi + jx) / wi - 0.5f);
+                const float ddy = static_cast<float>(-(yi + jy) / hi + 0.5f);
+                const float ddz = 1.0f;
+                const float inv = rcp_rn_normal(sqrt_rn_normal((ddx * ddx + ddy * ddy) + (1.0f * 1.0f + 0.0f * 0.0f)));   // 1 <= argument < 2
+                out_dx = ddx * inv; out_dy = ddy * inv; out_dz = ddz * inv;
             }
-            if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(!skip[k]));
+        };
+        // starts slot k's path along a primary direction (eye fixed at (0, 0, -20), main.cpp:129; Ray::color_ = 1, ray.h:17)
+        auto start_path = [&](int k, float ddx, float ddy, float ddz) {
+            q[k].dx = ddx; q[k].dy = ddy; q[k].dz = ddz;
+            q[k].ox = 0.0f; q[k].oy = 0.0f; q[k].oz = -20.0f;
+            tr[k] = tg[k] = tb[k] = 1.0f;
+            depth[k] = 0;
+        };
+        auto primary_ray = [&](int k, int pass_k) {
+            float ddx, ddy, ddz;
+            primary_dir(k, pass_k, ddx, ddy, ddz);
+            start_path(k, ddx, ddy, ddz);
+        };
+        if constexpr (!REGEN) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                tr[k] = tg[k] = tb[k] = 1.0f;
+                depth[k] = mrr;
+                if (PT_SLOT_ON(k) && !skip[k]) {
+                    primary_ray(k, pass);
+                } else {
+                    q[k].ox = q[k].oy = q[k].oz = 0.0f; q[k].dx = q[k].dy = 0.0f; q[k].dz = 1.0f;
+                }
+                if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(!skip[k]));
+            }
         }
+        // the pass of ray slot k's path: the wave's (a scalar) -- or, with regeneration, the lane's own
+        auto pass_of = [&](int k) {
+            if constexpr (REGEN) return cur_pass[k];
+            else return pass;
+        };
 
         for (;;) {
             bool valid[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) valid[k] = depth[k] < mrr && (tr[k] != 0.0f || tg[k] != 0.0f || tb[k] != 0.0f);   // Ray::IsValid, ray.h:52-54
+            if constexpr (REGEN) {
+                // Regeneration: a slot whose path is over takes its pixel's next pass -- after the adaptive skip of
+                // main.cpp:118-125, which sits out passes > 10 that are not multiples of 4 while the variance is low: the next
+                // one that runs is then the next multiple of 4.
+                // The primary-ray code (Philox, two double-precision divisions, a normalisation) costs about a third of a segment
+                // however few lanes run it, and on an open scene a quarter of the wave's paths end at every segment.  So rays
+                // are made IN ADVANCE and in batches: a slot keeps the primary direction of its pixel's next pass in store
+                // (`spare`), a slot whose path ends picks it up for the price of a few moves, and the code that makes directions
+                // runs -- for every slot that has none in store -- only once a.regen_min_dead slots are without one, or when a
+                // slot has ended its path with nothing in store.  A ray can be made ahead only if its pass is certain to be traced
+                // whatever the path under way still contributes: adaptive sampling off, or a pass <= 10, or a multiple of four
+                // (main.cpp:118-125); otherwise the slot decides -- and makes its ray -- when its path has ended.
+                bool gen[R], starve[R];
+                int gpass[R];
+                uint32_t n_gen = 0, n_starve = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    gen[k] = starve[k] = false;
+                    const bool picked = in_image[k] && !valid[k] && have_spare[k];
+                    if (picked) {
+                        start_path(k, spare[k][0], spare[k][1], spare[k][2]);
+                        cur_pass[k] = spare_pass[k];
+                        have_spare[k] = false;
+                        valid[k] = true;
+                    }
+                    int np = next_pass[k];
+                    if (in_image[k]) {
+                        if (!valid[k]) {   // path over, nothing in store: the adaptive skip of the next pass is decided now
+                            if (np > 10 && (np & 3) && lowvar[k]) np = (np + 3) & ~3;
+                            next_pass[k] = np;   // (final: lowvar only changes when this slot's own path contributes)
+                            starve[k] = gen[k] = np < pass_last;
+                        } else if (!have_spare[k]) {
+                            gen[k] = np < pass_last && (a.error < 0.0f || np <= 10 || (np & 3) == 0);
+                        }
+                    }
+                    gpass[k] = np;
+                    if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(picked));
+                    n_gen += __builtin_popcountll(__ballot(gen[k]));
+                    n_starve += __builtin_popcountll(__ballot(starve[k]));
+                }
+                if (n_starve > 0 || n_gen >= a.regen_min_dead) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        if (gen[k]) {
+                            float ddx, ddy, ddz;
+                            primary_dir(k, gpass[k], ddx, ddy, ddz);
+                            if (starve[k]) {
+                                start_path(k, ddx, ddy, ddz);
+                                cur_pass[k] = gpass[k];
+                            } else {
+                                spare[k][0] = ddx; spare[k][1] = ddy; spare[k][2] = ddz;
+                                spare_pass[k] = gpass[k];
+                                have_spare[k] = true;
+                            }
+                            next_pass[k] = gpass[k] + 1;
+                        }
+                        valid[k] = valid[k] || starve[k];
+                        if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(starve[k]));
+                    }
+                }
+            }
             if (!any_of(valid)) break;
             if constexpr (STATS) {
 #pragma unroll
@@ -1706,7 +1816,7 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
                     // another one (see below: nothing else of that segment survives it).
                     uint32_t w0 = 0, w1 = 0, w2 = 0, w3;
                     if (depth[k] + 1 < mrr || (m2v.x >= 2 && (m2v.y == 0 || m2v.z == 0)))
-                        philox4x32_10(rng_pixel(k), static_cast<uint32_t>(pass), static_cast<uint32_t>(depth[k]), 0u, a.seed, kPhiloxKey1,
+                        philox4x32_10(rng_pixel(k), static_cast<uint32_t>(pass_of(k)), static_cast<uint32_t>(depth[k]), 0u, a.seed, kPhiloxKey1,
                                       w0, w1, w2, w3);
                     int kind;
                     if (m2v.x == 0) {

@@ -9,6 +9,10 @@
 namespace pt {
 
 constexpr uint32_t kPhiloxKey1 = 0x50544831u;   // "PTH1": second Philox key word (the first is the seed)
+// Path regeneration (pt_kernels.hip: REGEN): the primary-ray code costs about a third of a segment whether one lane needs it or
+// all 64, so rays are made in advance and in batches: it runs once this many of the wave's ray slots have no ray in store (or one
+// has ended its path with none).
+constexpr uint32_t kRegenMinDead = 32;
 
 struct RenderArgs {
     const ClusterDesc *clusters;   // cull hierarchy (pt_scene.hpp: CullTables), read through the scalar cache
@@ -46,6 +50,7 @@ struct RenderArgs {
     int32_t may_leave_envelope;         // 0: no triangle of this scene can be hit outside the envelope, the integrator skips the test
     // A path's last segment (depth + 1 == mrr) can only contribute by hitting an emitter: the statistics-free, skybox-free
     // instantiations search the emitters alone first (CullTables::emis_*) and run the full search only for rays that hit one.
+    uint32_t regen_min_dead;            // skybox instantiations (path regeneration): primary rays are made once this many ray slots of the wave have none in store
     uint32_t last_segment_filter;       // 0 = off
     uint32_t emis_clusters, emis_large_w0, emis_bvh;
 #ifdef PT_BLOCK_PROFILE

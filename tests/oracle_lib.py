@@ -71,6 +71,7 @@ def lib():
         L.orc_probe_jitter.restype = C.c_double
         L.orc_probe_jitter.argtypes = [C.c_uint32]
         L.orc_scene_set_skybox.argtypes = [vp, C.c_char_p]
+        L.orc_probe_skybox.argtypes = [vp, C.c_int, fp, C.c_int, fp]
         L.orc_probe_acos_atan2.argtypes = [fp, fp, fp, C.c_int, C.c_int, fp, fp]
         L.orc_probe_sincos.argtypes = [fp, C.c_int, C.c_int, fp, fp]
         L.orc_probe_intersect.argtypes = [vp, C.c_int, fp, fp, C.c_float, C.c_float, fp]
@@ -135,6 +136,14 @@ class Scene:
         rc = lib().orc_scene_set_skybox(self.h, (path or "").encode())
         if rc != 0:
             raise RuntimeError(f"oracle: skybox could not be loaded ({rc})")
+
+    def sky_lookup(self, directions, trig=None):
+        """The skybox sample (r, g, b) / 256 a ray missing everything adds (scene.cpp:126-149), for unit directions [n, 3]."""
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        out = np.zeros_like(d)
+        if lib().orc_probe_skybox(self.h, len(d), _fp(d), TRIG_PORTABLE if trig is None else trig, _fp(out)) != 0:
+            raise RuntimeError("the scene has no skybox")
+        return out
 
     def closest_hits(self, origins, directions, eps=1e-4, threads=0):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

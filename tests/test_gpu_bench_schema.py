@@ -76,6 +76,16 @@ def test_bench_emits_one_valid_json_line():
     assert 0 < rb["useful_fraction"] < rb["frac_active_lanes"] < rb["frac"] <= 1.0
     assert 0.3 < rb["l1_hit_rate"] < 1.0 and rb["issue"]["instructions_per_wave_segment"] > 500
     assert rep["x64"]["node_rounds_per_wave_segment"] > 1
+    # BASELINE configs[2] (1024 spp) with the HBM bytes of that launch, and the open scene under a sky (path regeneration)
+    c2 = j["configs2_1024spp"]
+    assert "1024 spp" in c2["workload"] and c2["value"] > 100.0 and c2["steps"] == 3
+    assert c2["hbm"]["traffic_bytes"] is not None and c2["hbm"]["traffic_bytes"] > 0, c2["hbm"]["counters_source"]
+    assert c2["hbm"]["algorithmic_bytes"] == 1920 * 1080 * 56 + 270 * 56 and 0 < c2["hbm"]["frac"] < 0.05
+    sk = j["skybox_open"]
+    assert sk["value"] > 100.0 and sk["accumulators_bit_identical_to_oracle"] is True
+    assert 56 < sk["live_rays_per_wave_segment"] <= 64 and 1.0 < sk["segments_per_sample"] < 5.0 and sk["misses_per_sample"] > 0.5
+    assert sk["roofline"]["achieved"] is not None, sk["roofline"]["counters_source"]
+    assert sk["roofline"]["kernel"] == "pt::integrate_kernel<true,false,false,false,false,false>"
     # the C++ host alone on the same frame (pt_render -GPUS 1 -BENCH_STEPS): the same rate (a 2.8 ms frame at 8 spp: loose here)
     cx = j["cxx_frame"]["weak"]
     assert cx["cxx_frame"] and cx["bands"] == 1 and cx["transport"] == "none" and abs(cx["over_torch_leg"] - 1) < 0.15
@@ -115,6 +125,10 @@ def test_self_launch_two_ranks_and_too_many_gpus(tmp_path):
     assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["config"]["parallelism"] == "rowband2"
     cx = j["cxx_frame"]["weak"]       # the C++ host's two-band frame next to the two-rank torch leg (rehearsed: device copies)
     assert cx["bands"] == 2 and cx["transport"] == "device_copies" and cx["value"] > 100.0
+    # the diagnosis a first multi-device run should leave behind: every band's / rank's kernel time and the gather alone
+    assert len(cx["band_kernel_ms"]) == 2 and min(cx["band_kernel_ms"]) > 0 and cx["gather_alone_ms"] > 0
+    dg = j["multi_gpu_diagnosis"][0]
+    assert len(dg["kernel_ms_per_rank"]) == 2 and min(dg["kernel_ms_per_rank"]) > 0 and dg["gather_alone_ms"] > 0
     import torch
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, cwd=ROOT,

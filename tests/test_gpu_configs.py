@@ -190,3 +190,59 @@ def test_both_sides_of_the_small_big_switch_match_the_oracle(tmp_path, instances
             finally:
                 if thr is not None:
                     lib.pt_test_set_mutation(b"reset", 0.0)
+
+
+# ---- open scenes with a skybox: path regeneration (pt_kernels.hip: REGEN) -------------------------------------------------
+@pytest.mark.parametrize("big", [False, True], ids=["small", "big"])
+def test_open_scene_with_skybox_matches_the_oracle_for_every_path_length(tmp_path, big):
+    """Tor.obj without its back wall under a sky bitmap (tools/make_open_scene.py): most paths end on their first or second
+    segment, and the skybox instantiations let a lane whose path has ended start its pixel's next pass at once.  A lane is then
+    in a pass of its own -- its RNG counters, its adaptive-sampling skips (which jump to the next multiple of four) and the
+    order of its pixel's contributions must still be the reference's: the oracle's bits at -MRR 1 / 3 / 8, adaptive sampling
+    off and on (60 passes, so that pixels sit passes out), a ragged tile width, with and without statistics, and in two pass
+    slices (the second slice starts at a pass that is no multiple of four)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_open_scene as MO
+    d = str(tmp_path) + "/"
+    src, src_dir = "Tor.obj", None
+    if big:
+        src_dir, src, n = _replica(tmp_path, 5)
+        assert n > pt.BIG_SCENE_TRIANGLES
+    MO.generate(os.path.join(ROOT, "models"), d, name="Open.obj", source=src, source_dir=src_dir)
+    g = pt.Scene.load_obj(d, "Open.obj", device=0)
+    o = O.Scene.load(d, "Open.obj")
+    g.set_skybox(d + "sky.bmp")
+    o.set_skybox(d + "sky.bmp")
+    W, H, spp = 52, 36, 60
+    for mrr in (1, 3, 8):
+        for err in (-1.0, 0.02):
+            rs, rs2, rc, rst = O.render(o, W, H, spp, mrr, error=err)
+            assert rst["misses"] > W * H * spp // 50
+            if err > 0:
+                assert rst["samples_traced"] < 0.9 * W * H * spp            # adaptive sampling really skips
+            for want_stats in (True, False):
+                s, s2, c, st = g.render_host(W, H, spp, mrr, error=err, want_stats=want_stats)
+                assert np.array_equal(c, rc), (big, mrr, err, want_stats)
+                assert np.array_equal(_bits(s), _bits(rs)) and np.array_equal(_bits(s2), _bits(rs2)), (big, mrr, err, want_stats)
+                if want_stats:
+                    assert (st["samples_traced"], st["segments"], st["misses"], st["contributing"]) == \
+                           (rst["samples_traced"], rst["segments"], rst["misses"], rst["contributing"])
+            # two slices through a session: passes [0, 17) and [17, 60)
+            ses = pt.Session(g, W, H)
+            ses.render(0, 17, mrr, error=err)
+            ses.render(17, spp - 17, mrr, error=err)
+            s, s2, c = ses.read()
+            ses.close()
+            assert np.array_equal(c, rc) and np.array_equal(_bits(s), _bits(rs)) and np.array_equal(_bits(s2), _bits(rs2)), (big, mrr, err, "slices")
+
+
+def test_regeneration_keeps_the_lanes_busy(tmp_path):
+    """What regeneration is for: on the open scene a wave-segment carries nearly 64 live rays instead of half that."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_open_scene as MO
+    d = str(tmp_path) + "/"
+    MO.generate(os.path.join(ROOT, "models"), d)
+    g = pt.Scene.load_obj(d, "TorOpen.obj", device=0)
+    g.set_skybox(d + "sky.bmp")
+    st = g.render_host(640, 360, 32, 8, error=-1.0)[3]
+    assert st["segments"] / st["wave_segments"] > 56, st

@@ -155,12 +155,34 @@ OP_KERNEL(v_mul_legacy_f32, "v_mul_legacy_f32 %0, %0, %8\n v_mul_legacy_f32 %1, 
 OP_KERNEL(v_max_f32_via_fma_test, "v_fma_f32 %0, %0, %8, %9 clamp\n v_fma_f32 %1, %1, %8, %9 clamp\n v_fma_f32 %2, %2, %8, %9 clamp\n v_fma_f32 %3, %3, %8, %9 clamp\n", "memory")
 OP_KERNEL(v_mul_f32_omod, "v_mul_f32_e64 %0, %0, %8 mul:2\n v_mul_f32_e64 %1, %1, %8 mul:2\n v_mul_f32_e64 %2, %2, %8 mul:2\n v_mul_f32_e64 %3, %3, %8 mul:2\n", "memory")
 
+// round 4: the packed 16-bit forms a half-precision slab test of the box tree would use
+OP_KERNEL(v_pk_fma_f16, "v_pk_fma_f16 %0, %0, %8, %9\n v_pk_fma_f16 %1, %1, %8, %9\n v_pk_fma_f16 %2, %2, %8, %9\n v_pk_fma_f16 %3, %3, %8, %9\n", "memory")
+OP_KERNEL(v_pk_max_f16, "v_pk_max_f16 %0, %0, %8\n v_pk_max_f16 %1, %1, %8\n v_pk_max_f16 %2, %2, %8\n v_pk_max_f16 %3, %3, %8\n", "memory")
+OP_KERNEL(v_pk_min_f16, "v_pk_min_f16 %0, %0, %8\n v_pk_min_f16 %1, %1, %8\n v_pk_min_f16 %2, %2, %8\n v_pk_min_f16 %3, %3, %8\n", "memory")
+OP_KERNEL(v_pk_add_f16, "v_pk_add_f16 %0, %0, %8\n v_pk_add_f16 %1, %1, %8\n v_pk_add_f16 %2, %2, %8\n v_pk_add_f16 %3, %3, %8\n", "memory")
+OP_KERNEL(v_pk_mul_f16, "v_pk_mul_f16 %0, %0, %8\n v_pk_mul_f16 %1, %1, %8\n v_pk_mul_f16 %2, %2, %8\n v_pk_mul_f16 %3, %3, %8\n", "memory")
+OP_KERNEL(v_pk_mad_i16, "v_pk_mad_i16 %0, %0, %8, %9\n v_pk_mad_i16 %1, %1, %8, %9\n v_pk_mad_i16 %2, %2, %8, %9\n v_pk_mad_i16 %3, %3, %8, %9\n", "memory")
+OP_KERNEL(v_pk_max_i16, "v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_max_i16 %3, %3, %8\n", "memory")
+OP_KERNEL(v_pk_sub_i16, "v_pk_sub_i16 %0, %0, %8\n v_pk_sub_i16 %1, %1, %8\n v_pk_sub_i16 %2, %2, %8\n v_pk_sub_i16 %3, %3, %8\n", "memory")
+OP_KERNEL(v_pk_lshrrev_b16, "v_pk_lshrrev_b16 %0, 8, %8\n v_pk_lshrrev_b16 %1, 8, %8\n v_pk_lshrrev_b16 %2, 8, %8\n v_pk_lshrrev_b16 %3, 8, %8\n", "memory")
+OP_KERNEL(v_and_b32_lit, "v_and_b32 %0, 0xff00ff, %8\n v_and_b32 %1, 0xff00ff, %8\n v_and_b32 %2, 0xff00ff, %8\n v_and_b32 %3, 0xff00ff, %8\n", "memory")
+OP_KERNEL(v_cvt_pkrtz_f16_f32, "v_cvt_pkrtz_f16_f32 %0, %8, %9\n v_cvt_pkrtz_f16_f32 %1, %8, %9\n v_cvt_pkrtz_f16_f32 %2, %8, %9\n v_cvt_pkrtz_f16_f32 %3, %8, %9\n", "memory")
+OP_KERNEL(v_max_f16, "v_max_f16 %0, %0, %8\n v_max_f16 %1, %1, %8\n v_max_f16 %2, %2, %8\n v_max_f16 %3, %3, %8\n", "memory")
+OP_KERNEL(v_fma_f16, "v_fma_f16 %0, %0, %8, %9\n v_fma_f16 %1, %1, %8, %9\n v_fma_f16 %2, %2, %8, %9\n v_fma_f16 %3, %3, %8, %9\n", "memory")
+OP_KERNEL(v_alignbyte_b32, "v_alignbyte_b32 %0, %8, %8, 1\n v_alignbyte_b32 %1, %8, %8, 1\n v_alignbyte_b32 %2, %8, %8, 1\n v_alignbyte_b32 %3, %8, %8, 1\n", "memory")
+OP_KERNEL(v_lshrrev_b32_imm, "v_lshrrev_b32 %0, 8, %8\n v_lshrrev_b32 %1, 8, %8\n v_lshrrev_b32 %2, 8, %8\n v_lshrrev_b32 %3, 8, %8\n", "memory")
+OP_KERNEL(mix_pkfma_and, "v_pk_fma_f16 %0, %0, %8, %9\n v_and_b32 %1, 0xff00ff, %8\n v_pk_fma_f16 %2, %2, %8, %9\n v_and_b32 %3, 0xff00ff, %8\n", "memory")
+
 struct Entry { const char *name; void (*fn)(uint32_t *, int); int per_group; };
 #define E(n) {#n, k_##n, 4}
 
 int main(int argc, char **argv) {
     double mhz = 2400.0;
-    for (int i = 1; i + 1 < argc; ++i) if (!std::strcmp(argv[i], "--mhz")) mhz = std::atof(argv[i + 1]);
+    const char *only = nullptr;   // --only a,b,c: just these (and v_add_u32, the reference)
+    for (int i = 1; i + 1 < argc; ++i) {
+        if (!std::strcmp(argv[i], "--mhz")) mhz = std::atof(argv[i + 1]);
+        if (!std::strcmp(argv[i], "--only")) only = argv[i + 1];
+    }
     const std::vector<Entry> ops = {
         E(v_add_u32), E(v_mov_b32), E(v_mul_f32), E(v_fma_f32), E(v_fmac_f32), E(v_pk_fma_f32), E(v_pk_mul_f32), E(v_fma_f64), E(v_mul_f64),
         E(v_add_f64), E(v_rcp_f32), E(v_rsq_f32), E(v_sqrt_f32), E(v_mad_u64_u32), E(v_mul_lo_u32), E(v_mul_hi_u32), E(v_mul_u32_u24),
@@ -169,7 +191,8 @@ int main(int argc, char **argv) {
         E(v_readlane), E(v_readfirstlane), E(v_mov_dpp), E(v_add_dpp), E(v_mbcnt), E(s_add_u32), E(s_and_b64), E(s_mov_b32), E(s_bcnt1),
         E(s_nop), E(s_waitcnt), E(ds_read_b32), E(ds_write_b32), E(ds_bpermute), E(mix_valu_salu), E(mix_fma_cvt),
         E(v_sub_f32), E(v_add_f32), E(v_mul_f32_sgpr), E(v_mul_f32_lit), E(v_mul_f32_abs), E(v_fma_f32_sgpr), E(v_fma_f32_neg), E(v_mov_b32_sgpr), E(v_mov_b32_lit), E(v_and_b32), E(v_or_b32), E(v_xor_b32), E(v_not_b32), E(v_lshlrev_b32), E(v_lshrrev_b32), E(v_sub_u32), E(v_lshl_add_u32), E(v_add3_u32), E(v_or3_b32), E(v_lshl_or_b32), E(v_and_or_b32), E(v_add_u32_sdwa), E(v_max_f32), E(v_min3_f32), E(v_med3_f32), E(v_min_u32), E(v_div_scale_f32), E(v_div_fmas_f32), E(v_div_fixup_f32), E(v_cmp_lt_f32_e64), E(v_cmp_ne_u32_vcc), E(v_cmp_class_f32), E(v_cndmask_e64_vcc), E(v_writelane), E(v_bcnt_u32), E(v_ffbl_b32), E(v_mbcnt_hi), E(v_mul_lo_u16), E(v_cvt_u32_f32), E(v_lshl_add_u64), E(cmp_cndmask_vcc), E(cmp_cndmask_sgpr), E(cndmask_vcc_after_salu), E(mix_fma_min), E(mix_fma_salu_lds),
-        E(cmp_3cndmask_vcc), E(cmp_add_2cndmask_vcc), E(cmp_3cndmask_e64_vcc), E(cmp_3cndmask_sgpr), E(addc_vcc), E(div_fmas_vcc), E(cbranch_vccz), E(s_and_saveexec), E(s_cbranch_scc), E(s_cbranch_execz), E(v_mul_f32_dep_sgprmix), E(v_lshlrev_b32_v), E(v_add_u32_const), E(v_mul_f32_const), E(v_fma_f32_const), E(v_ashrrev_i32), E(v_mad_u32_u24), E(v_mul_legacy_f32), E(v_max_f32_via_fma_test), E(v_mul_f32_omod)};
+        E(cmp_3cndmask_vcc), E(cmp_add_2cndmask_vcc), E(cmp_3cndmask_e64_vcc), E(cmp_3cndmask_sgpr), E(addc_vcc), E(div_fmas_vcc), E(cbranch_vccz), E(s_and_saveexec), E(s_cbranch_scc), E(s_cbranch_execz), E(v_mul_f32_dep_sgprmix), E(v_lshlrev_b32_v), E(v_add_u32_const), E(v_mul_f32_const), E(v_fma_f32_const), E(v_ashrrev_i32), E(v_mad_u32_u24), E(v_mul_legacy_f32), E(v_max_f32_via_fma_test), E(v_mul_f32_omod),
+        E(v_pk_fma_f16), E(v_pk_max_f16), E(v_pk_min_f16), E(v_pk_add_f16), E(v_pk_mul_f16), E(v_pk_mad_i16), E(v_pk_max_i16), E(v_pk_sub_i16), E(v_pk_lshrrev_b16), E(v_and_b32_lit), E(v_cvt_pkrtz_f16_f32), E(v_max_f16), E(v_fma_f16), E(v_alignbyte_b32), E(v_lshrrev_b32_imm), E(mix_pkfma_and)};
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -183,6 +206,10 @@ int main(int argc, char **argv) {
     std::printf("%-18s %10s %10s %10s %12s\n", "instruction", "1 wave", "2 waves", "6 waves", "vs v_add_u32");
     double ref = 0;
     for (const Entry &e : ops) {
+        if (only && std::strcmp(e.name, "v_add_u32") != 0) {
+            const std::string list = std::string(",") + only + ",", key = std::string(",") + e.name + ",";
+            if (list.find(key) == std::string::npos) continue;
+        }
         double cyc[3];
         const int waves[3] = {1, 2, 6};
         for (int w = 0; w < 3; ++w) {

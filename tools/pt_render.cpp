@@ -179,10 +179,34 @@ int main(int argc, char **argv) {
         if (pt_frame_wait(frame) != PT_OK) return die("pt_render");
         const double dt = secs(a, clk::now());
         const double samples = static_cast<double>(o.width) * o.height * o.rays_per_pixel * o.bench_steps;
+        // With more than one band: one more frame, untimed, taken apart -- every band's own kernel time (HIP events on its
+        // stream), then, with all kernels done, the gather alone on the host's clock -- so that the first run on several devices
+        // says where the time went and not only how long it took.
+        std::string diagnosis;
+        if (devices.size() > 1) {
+            pt_render_stats st;
+            rp.pass_begin = 0;
+            rp.pass_count = o.rays_per_pixel;
+            std::vector<float> band_ms(devices.size(), -1.0f);
+            if (pt_frame_clear(frame) != PT_OK || pt_frame_render(frame, &rp, &st) != PT_OK || pt_frame_wait(frame) != PT_OK ||
+                pt_frame_band_kernel_ms(frame, band_ms.data()) != PT_OK)
+                return die("pt_render");
+            const clk::time_point g0 = clk::now();
+            if (pt_frame_gather(frame) != PT_OK || pt_frame_wait(frame) != PT_OK) return die("pt_render");
+            const double gather_ms = secs(g0, clk::now()) * 1e3;
+            char buf[64];
+            diagnosis = ", \"band_kernel_ms\": [";
+            for (size_t b = 0; b < band_ms.size(); ++b) {
+                std::snprintf(buf, sizeof buf, "%s%.3f", b ? ", " : "", static_cast<double>(band_ms[b]));
+                diagnosis += buf;
+            }
+            std::snprintf(buf, sizeof buf, "], \"gather_alone_ms\": %.3f", gather_ms);
+            diagnosis += buf;
+        }
         std::printf("{\"cxx_frame\": true, \"value\": %.3f, \"unit\": \"Msamples/s\", \"ms_per_step\": %.4f, \"steps\": %d, \"warmup\": %d, "
-                    "\"bands\": %zu, \"devices_visible\": %d, \"transport\": \"%s\", \"width\": %d, \"height\": %d, \"spp\": %d, \"mrr\": %d, \"error\": %g}\n",
+                    "\"bands\": %zu, \"devices_visible\": %d, \"transport\": \"%s\", \"width\": %d, \"height\": %d, \"spp\": %d, \"mrr\": %d, \"error\": %g%s}\n",
                     samples / dt / 1e6, dt / o.bench_steps * 1e3, o.bench_steps, o.bench_warmup, devices.size(), n_dev, transport_name, o.width, o.height,
-                    o.rays_per_pixel, o.max_ray_reflections, static_cast<double>(o.error));
+                    o.rays_per_pixel, o.max_ray_reflections, static_cast<double>(o.error), diagnosis.c_str());
         pt_frame_destroy(frame);
         pt_scene_destroy(scene);
         return 0;
