@@ -235,10 +235,7 @@ void fill_scene_args(const pt_scene *scene, float eps, pt::RenderArgs &a) {
 #ifdef PT_TEST_HOOKS
     if (pt::g_cull_mutation.no_last_segment_filter) a.last_segment_filter = 0;
 #endif
-    a.regen_min_dead = pt::kRegenMinDead;
-#ifdef PT_TEST_HOOKS
-    if (g_regen_min_dead > 0) a.regen_min_dead = static_cast<uint32_t>(g_regen_min_dead);
-#endif
+    a.regen_min_dead = 64;   // (set per launch from -MRR: enqueue_render)
     a.emis_clusters = t.emis_clusters;
     a.emis_large_w0 = t.emis_large_w0;
     a.emis_bvh = t.emis_bvh ? 1u : 0u;
@@ -267,6 +264,10 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
     a.sum2 = d_sum2;
     a.count = d_count;
     a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+    a.regen_min_dead = pt::regen_min_dead_for(p->max_ray_reflections);
+#ifdef PT_TEST_HOOKS
+    if (g_regen_min_dead > 0) a.regen_min_dead = static_cast<uint32_t>(g_regen_min_dead);
+#endif
     a.pass_begin = p->pass_begin; a.pass_count = p->pass_count; a.mrr = p->max_ray_reflections;
     a.error = p->error; a.seed = p->seed;
     if (p->row_end == p->row_begin) return PT_OK;
@@ -1080,6 +1081,31 @@ int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, i
 // Test build only (libpt_testhooks.so).  family: "sphere_r2", "m0", "k12", "a_max", "quad_slack" (scale on that family of
 // conservative margins; 1 = as shipped), "no_absorb" (0/1), "items_per_slot" (scheduler), "reset".  Affects scenes whose
 // cull tables are built afterwards.
+// Test builds only: both forms of the box tree's child test (pt_kernels.hip: box_children_kept / box_children_kept_h) on n
+// caller-supplied items -- nodes: n x 64 bytes (BvhNode), rays: n x 6 floats (origin, unit direction), t_best: n floats --
+// out: 2 n masks (float form, half-precision form).  Host pointers; device 0.
+int pt_test_box_masks(const void *nodes, const float *rays, const float *t_best, float err, int32_t n, uint32_t *out) {
+    if (!nodes || !rays || !t_best || !out || n < 0) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return PT_OK;
+    PT_HIP_TRY(hipSetDevice(0));
+    void *d_nodes = nullptr, *d_rays = nullptr, *d_t = nullptr, *d_out = nullptr;
+    const size_t nn = static_cast<size_t>(n);
+    hipError_t e = hipMalloc(&d_nodes, nn * 64);
+    if (e == hipSuccess) e = hipMalloc(&d_rays, nn * 24);
+    if (e == hipSuccess) e = hipMalloc(&d_t, nn * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_out, nn * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_nodes, nodes, nn * 64, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, nn * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_t, t_best, nn * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pt::launch_box_masks(static_cast<const pt::BvhNode *>(d_nodes), static_cast<const float *>(d_rays), static_cast<const float *>(d_t), err, n,
+                                                  static_cast<uint32_t *>(d_out), nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, nn * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_nodes); (void)hipFree(d_rays); (void)hipFree(d_t); (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(e, "pt_test_box_masks");
+    return PT_OK;
+}
+
 int pt_test_set_mutation(const char *family, double value) {
     if (!family) return PT_ERR_INVALID_ARGUMENT;
     const std::string f = family;

@@ -523,6 +523,110 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
     return m;
 }
 
+#ifndef PT_BOX_F16
+#define PT_BOX_F16 0   // 1: the box tree's child boxes are tested two at a time in packed half precision (box_children_kept_h)
+#endif
+// ---------------------------------------------------------------------------------------------------------------
+// The same test in PACKED HALF PRECISION, two children per instruction (round 4; profiles/r04_ab_logs.txt slab16).
+//   * The ray is recentred on the point where it enters the node's frame (t_enter = the latest of the three near planes of the
+//     frame [0, 255]^3) and scaled by a power of two S: T = (t - t_enter) S, with S chosen from the exponent of the smallest
+//     |A| so that the frame's extent along the ray, at most 255 min|A|, is below 2^-10.  What the test compares then lies in
+//     [0, 2^-10), where half precision resolves 2^-21 or better: an eighth to a quarter of the smallest quantisation step.
+//   * A child plane byte q is used AS IT IS: zero-extended to 16 bits it is the half-precision subnormal q 2^-24, and
+//     v_pk_fma_f16 multiplies it exactly (half-precision denormals are on: the kernel descriptor's default); the factor 2^24 goes
+//     into the coefficient.  A ray travelling down an axis sees the frame mirrored (q -> 255 - q = ~q), so every coefficient is
+//     non-negative and every offset non-positive, and the DIRECTED roundings are free: v_cvt_pkrtz rounds the entry planes'
+//     coefficient down and the exit planes' offset up, one added to the bit pattern gives the other two.
+//   * Both roundings of a comparison (the two fused multiply-adds, half an ulp of a value below 2^-10 each: 2^-21 (1 + 2^-6)) and
+//     the float32 stage's own error (3 err (|B| + 255 |A|)_max S) go into the entry planes' offset once per node, like the
+//     allowance of the float version.
+//   * Overflow is conservative by construction: a coefficient beyond the half-precision range saturates at 65504 (entry: a lower
+//     bound) and its successor is +inf (exit: an upper bound); inf * 0 and inf - inf give NaNs, which max / min skip and whose
+//     difference has a clear sign bit: kept.
+// CONSERVATIVE like the float test (tests/bvh_emulation.py: children_kept_f16 restates it operation for operation;
+// tests/test_cull_tables_host.py holds it to the chain test), a little looser: 2 % more node visits and 8 % more (ray, triangle)
+// pairs on the x64 replica (tools/slab_f16_study.py).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk_fma_h(uint32_t a, uint32_t q, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(q), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max_h(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_min_h(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_sub_h(uint32_t a, uint32_t b) {   // a - b in both halves
+    uint32_t d;
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_rtz2(float x) {   // (x, x) as two halves, rounded toward zero
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x, x));
+}
+__device__ __forceinline__ uint32_t box_children_kept_h(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
+                                                        float ix, float iy, float iz, float t_best, float err) {
+    const float step = __uint_as_float((q0.w & 0xFFu) << 23);
+    const float ax = step * ix, ay = step * iy, az = step * iz;
+    const float bx = (__uint_as_float(q0.x) - r.ox) * ix, by = (__uint_as_float(q0.y) - r.oy) * iy, bz = (__uint_as_float(q0.z) - r.oz) * iz;
+    // the frame's near plane along every axis, the point of entry, the scale
+    const float lx = __builtin_fminf(bx, __builtin_fmaf(255.0f, ax, bx)), ly = __builtin_fminf(by, __builtin_fmaf(255.0f, ay, by)),
+                lz = __builtin_fminf(bz, __builtin_fmaf(255.0f, az, bz));
+    const float t_enter = __builtin_fmaxf(__builtin_fmaxf(lx, ly), lz);
+    const float amin = __builtin_fminf(__builtin_fminf(__builtin_fabsf(ax), __builtin_fabsf(ay)), __builtin_fabsf(az));
+    const float s24 = __uint_as_float(0x81800000u - (__float_as_uint(amin) & 0x7F800000u));   // 2^(5 - exponent of amin): amin s24 in [2^5, 2^6)
+    const float s = s24 * 5.9604644775390625e-08f;                                            // 2^-24
+    // the allowance, in T units: the float32 stage's own rounding (reciprocal to an ulp, products, differences: within err of
+    // |B| + 255 |A| per plane as in the float test, taken with half as much again for the recentring's extra difference) + the two
+    // half-precision roundings of a comparison, 2^-21 (1 + 2^-6); both scale with err (test hooks: CullMutation::box_err)
+    const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx), __builtin_fabsf(by)), __builtin_fabsf(bz));
+    const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ax), __builtin_fabsf(ay)), __builtin_fabsf(az));
+    const float m = __builtin_fmaf(3.0f * err * __builtin_fmaf(255.0f, amax, bmax), s, err * (4.842877388e-07f / 5.0e-07f));
+    const uint32_t one = 0x00010001u;                      // one ulp away from zero, both halves
+    const uint32_t anx = pk_rtz2(__builtin_fabsf(ax) * s24), any_ = pk_rtz2(__builtin_fabsf(ay) * s24), anz = pk_rtz2(__builtin_fabsf(az) * s24);
+    const uint32_t afx = anx + one, afy = any_ + one, afz = anz + one;
+    const float dx = lx - t_enter, dy = ly - t_enter, dz = lz - t_enter;   // <= 0
+    const uint32_t bfx = pk_rtz2(dx * s), bfy = pk_rtz2(dy * s), bfz = pk_rtz2(dz * s);
+    const uint32_t bnx = pk_rtz2(__builtin_fmaf(dx, s, -m)) + one, bny = pk_rtz2(__builtin_fmaf(dy, s, -m)) + one, bnz = pk_rtz2(__builtin_fmaf(dz, s, -m)) + one;
+    const float tm = __builtin_fmaf(-t_enter, s, -m), tb = (t_best - t_enter) * s;
+    const uint32_t tmin = pk_rtz2(__builtin_fmaf(__builtin_fabsf(tm), -1.953125e-03f, tm));    // rounded down whatever its sign (2^-9 of slack)
+    const uint32_t tbest = pk_rtz2(__builtin_fmaf(__builtin_fabsf(tb), 1.953125e-03f, tb));    // rounded up
+    // rows: near = lower planes for a ray going up the axis, else the mirrored upper planes (~hi); far likewise.  One v_bitop3 each.
+    const uint32_t mx = static_cast<uint32_t>(__float_as_int(ix) >> 31), my = static_cast<uint32_t>(__float_as_int(iy) >> 31), mz = static_cast<uint32_t>(__float_as_int(iz) >> 31);
+    auto sel = [](uint32_t lo, uint32_t hi, uint32_t mk) { return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(lo, hi, mk, 0x72)); };   // mk ? ~hi : lo
+    const uint32_t nx[2] = {sel(q1.x, q2.z, mx), sel(q1.y, q2.w, mx)}, fx[2] = {sel(q2.z, q1.x, mx), sel(q2.w, q1.y, mx)};
+    const uint32_t ny[2] = {sel(q1.z, q3.x, my), sel(q1.w, q3.y, my)}, fy[2] = {sel(q3.x, q1.z, my), sel(q3.y, q1.w, my)};
+    const uint32_t nz[2] = {sel(q2.x, q3.z, mz), sel(q2.y, q3.w, mz)}, fz[2] = {sel(q3.z, q2.x, mz), sel(q3.w, q2.y, mz)};
+    uint32_t dd[2][2];   // [word][parity]: t_out - t_in of children (4 word + parity, 4 word + parity + 2) in the (low, high) half
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            // bytes (0, 2) or (1, 3) of a row word as two 16-bit numbers: one v_and_b32 / one v_pk_lshrrev_b16
+            auto un = [&](uint32_t v) {
+                if (par == 0) return v & 0x00FF00FFu;
+                uint32_t d;
+                asm("v_pk_lshrrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(v));   // (op_sel_hi: the inline 8 shifts the high half too)
+                return d;
+            };
+            const uint32_t tnx = pk_fma_h(anx, un(nx[w]), bnx), tny = pk_fma_h(any_, un(ny[w]), bny), tnz = pk_fma_h(anz, un(nz[w]), bnz);
+            const uint32_t tfx = pk_fma_h(afx, un(fx[w]), bfx), tfy = pk_fma_h(afy, un(fy[w]), bfy), tfz = pk_fma_h(afz, un(fz[w]), bfz);
+            const uint32_t t_in = pk_max_h(pk_max_h(tnx, tny), pk_max_h(tnz, tmin));
+            const uint32_t t_out = pk_min_h(pk_min_h(tfx, tfy), pk_min_h(tfz, tbest));
+            dd[w][par] = pk_sub_h(t_out, t_in);
+        }
+    }
+    // sign bits -> mask of the children to DROP: child 4 w + par + 2 h sits in bit 15 + 16 h of dd[w][par]
+    const uint32_t acc = ((dd[0][0] >> 15) & 0x00010001u) | ((dd[0][1] >> 14) & 0x00020002u) | ((dd[1][0] >> 11) & 0x00100010u) | ((dd[1][1] >> 10) & 0x00200020u);
+    return ~(acc | (acc >> 14)) & 0xFFu;
+}
+
 // Scene::TraceRay's triangle loop exactly as the reference runs it (scene.cpp:116-120): every triangle, in index order,
 // through Triangle::Intersect for this lane's ray; returns the closest-hit key (~0 = miss).  Wave-uniform control flow.
 // Only the verification build calls it.
@@ -1126,7 +1230,12 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     const float ix = lds.rinv.v[0][src], iy = lds.rinv.v[1][src], iz = lds.rinv.v[2][src];
+#if PT_BOX_F16
+                    static_assert(!PT_BOX_SPREAD, "the half-precision test handles a node's eight children in one lane");
+                    if (shift == 0u) m8 = box_children_kept_h(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err);
+#else
                     if (shift == 0u) m8 = box_children_kept<8>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err);
+#endif
                     else if (shift == 1u) m8 = box_children_kept<4>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err, sub);
                     else if (shift == 2u) m8 = box_children_kept<2>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err, sub);
                     else m8 = box_children_kept<1>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err, sub);
@@ -1442,17 +1551,12 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
     Ray q[R];
     float tr[R], tg[R], tb[R];   // Ray::color_ (throughput), ray.h:17
     int depth[R];
-    int cur_pass[R], next_pass[R];   // REGEN: the pass slot k's path belongs to / the next one its pixel has no ray for yet
-    float spare[R][3];               // REGEN: primary direction made in advance for pass spare_pass[k], if have_spare[k]
-    int spare_pass[R];
-    bool have_spare[R];
+    int cur_pass[R], next_pass[R];   // REGEN: the pass slot k's path belongs to / the next one its pixel has to run
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         tr[k] = tg[k] = tb[k] = 1.0f;
         depth[k] = mrr;
-        cur_pass[k] = next_pass[k] = spare_pass[k] = pass_first;
-        have_spare[k] = false;
-        spare[k][0] = spare[k][1] = 0.0f; spare[k][2] = 1.0f;
+        cur_pass[k] = next_pass[k] = pass_first;
         q[k].ox = q[k].oy = q[k].oz = 0.0f; q[k].dx = q[k].dy = 0.0f; q[k].dz = 1.0f;
     }
     for (int pass = pass_first; REGEN ? pass == pass_first : pass < pass_last; ++pass) {   // (REGEN: one trip, the loop inside runs all passes)
@@ -1586,60 +1690,41 @@ __global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!N
                 // Regeneration: a slot whose path is over takes its pixel's next pass -- after the adaptive skip of
                 // main.cpp:118-125, which sits out passes > 10 that are not multiples of 4 while the variance is low: the next
                 // one that runs is then the next multiple of 4.
+                // Regeneration: a slot whose path is over takes its pixel's next pass -- after the adaptive skip of
+                // main.cpp:118-125, which sits out passes > 10 that are not multiples of 4 while the variance is low: the next
+                // one that runs is then the next multiple of 4.
                 // The primary-ray code (Philox, two double-precision divisions, a normalisation) costs about a third of a segment
-                // however few lanes run it, and on an open scene a quarter of the wave's paths end at every segment.  So rays
-                // are made IN ADVANCE and in batches: a slot keeps the primary direction of its pixel's next pass in store
-                // (`spare`), a slot whose path ends picks it up for the price of a few moves, and the code that makes directions
-                // runs -- for every slot that has none in store -- only once a.regen_min_dead slots are without one, or when a
-                // slot has ended its path with nothing in store.  A ray can be made ahead only if its pass is certain to be traced
-                // whatever the path under way still contributes: adaptive sampling off, or a pass <= 10, or a multiple of four
-                // (main.cpp:118-125); otherwise the slot decides -- and makes its ray -- when its path has ended.
-                bool gen[R], starve[R];
-                int gpass[R];
-                uint32_t n_gen = 0, n_starve = 0;
+                // however few lanes run it, so it runs only once a.regen_min_dead slots of the wave wait for a path, or when no
+                // ray of the wave is alive (a.regen_min_dead = 64: the wave's passes stay in step, as without regeneration).  The
+                // host sets it per launch (enqueue_render): 1 from -MRR 5 up, 64 below -- measured on Tor.obj without its back
+                // wall, 1080p x 64 spp (profiles/r04_regen_sweep.jsonl; Msamples/s at 1 / 16 / 32 / 64): -MRR 8 6 980 / 6 650 / 6 210 /
+                // 5 350, -MRR 5 8 250 / 8 030 / 7 710 / 8 100, -MRR 3 11 260 / 11 360 / 12 740 / 13 390.  Making the rays in advance and
+                // in batches (a ray in store per slot) was built and measured too: +1 % at -MRR 8, -16 % at -MRR 3 still -- a slot
+                // that ends two paths in a row has nothing in store, and some slot of 64 nearly always does (r04_ab_logs.txt, regen2).
+                // Which iteration a path starts in changes nothing about it: the frames are the same for every setting.
+                uint32_t n_wait = 0;
+                bool wants[R];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    gen[k] = starve[k] = false;
-                    const bool picked = in_image[k] && !valid[k] && have_spare[k];
-                    if (picked) {
-                        start_path(k, spare[k][0], spare[k][1], spare[k][2]);
-                        cur_pass[k] = spare_pass[k];
-                        have_spare[k] = false;
-                        valid[k] = true;
+                    wants[k] = false;
+                    if (!valid[k] && in_image[k]) {
+                        int np = next_pass[k];
+                        if (np > 10 && (np & 3) && lowvar[k]) np = (np + 3) & ~3;
+                        next_pass[k] = np;                 // (the skip is final: lowvar only changes when this slot's own path contributes)
+                        wants[k] = np < pass_last;
                     }
-                    int np = next_pass[k];
-                    if (in_image[k]) {
-                        if (!valid[k]) {   // path over, nothing in store: the adaptive skip of the next pass is decided now
-                            if (np > 10 && (np & 3) && lowvar[k]) np = (np + 3) & ~3;
-                            next_pass[k] = np;   // (final: lowvar only changes when this slot's own path contributes)
-                            starve[k] = gen[k] = np < pass_last;
-                        } else if (!have_spare[k]) {
-                            gen[k] = np < pass_last && (a.error < 0.0f || np <= 10 || (np & 3) == 0);
-                        }
-                    }
-                    gpass[k] = np;
-                    if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(picked));
-                    n_gen += __builtin_popcountll(__ballot(gen[k]));
-                    n_starve += __builtin_popcountll(__ballot(starve[k]));
+                    n_wait += __builtin_popcountll(__ballot(wants[k]));
                 }
-                if (n_starve > 0 || n_gen >= a.regen_min_dead) {
+                if (n_wait >= a.regen_min_dead || (n_wait > 0 && !any_of(valid))) {
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        if (gen[k]) {
-                            float ddx, ddy, ddz;
-                            primary_dir(k, gpass[k], ddx, ddy, ddz);
-                            if (starve[k]) {
-                                start_path(k, ddx, ddy, ddz);
-                                cur_pass[k] = gpass[k];
-                            } else {
-                                spare[k][0] = ddx; spare[k][1] = ddy; spare[k][2] = ddz;
-                                spare_pass[k] = gpass[k];
-                                have_spare[k] = true;
-                            }
-                            next_pass[k] = gpass[k] + 1;
+                        if (wants[k]) {
+                            cur_pass[k] = next_pass[k];
+                            primary_ray(k, next_pass[k]);
+                            next_pass[k] = next_pass[k] + 1;
                         }
-                        valid[k] = valid[k] || starve[k];
-                        if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(starve[k]));
+                        valid[k] = valid[k] || wants[k];
+                        if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(wants[k]));
                     }
                 }
             }
@@ -2000,6 +2085,28 @@ __global__ __launch_bounds__(kBlock, BIG ? PT_BIG_WAVES : PT_WAVES_PER_SIMD) voi
         hit_index[i] = hit[0];
         hit_t[i] = best[0];
     }
+}
+
+// Diagnostic (test builds call it through pt_test_box_masks): both forms of the box tree's child test on caller-supplied
+// (node, ray, t_best) items, one item per lane -- out[2 i] = box_children_kept<8>, out[2 i + 1] = box_children_kept_h.
+__global__ __launch_bounds__(kBlock) void box_masks_kernel(const BvhNode *__restrict__ nodes, const float *__restrict__ rays,
+                                                           const float *__restrict__ t_best, float err, int n, uint32_t *__restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *np = reinterpret_cast<const uint4 *>(nodes + i);
+    const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    Ray r;
+    r.ox = rays[6 * i]; r.oy = rays[6 * i + 1]; r.oz = rays[6 * i + 2];
+    r.dx = rays[6 * i + 3]; r.dy = rays[6 * i + 4]; r.dz = rays[6 * i + 5];
+    const float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
+    const uint32_t exists = (2u << ((q0.w >> 8) & 7u)) - 1u;
+    out[2 * i] = box_children_kept<8>(q0, q1, q2, q3, r, ix, iy, iz, t_best[i], err) & exists;
+    out[2 * i + 1] = box_children_kept_h(q0, q1, q2, q3, r, ix, iy, iz, t_best[i], err) & exists;
+}
+hipError_t launch_box_masks(const BvhNode *d_nodes, const float *d_rays, const float *d_t_best, float err, int n, uint32_t *d_out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(box_masks_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_nodes, d_rays, d_t_best, err, n, d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, const float *d_directions, int n_rays,

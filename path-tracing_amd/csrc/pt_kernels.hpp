@@ -9,10 +9,11 @@
 namespace pt {
 
 constexpr uint32_t kPhiloxKey1 = 0x50544831u;   // "PTH1": second Philox key word (the first is the seed)
-// Path regeneration (pt_kernels.hip: REGEN): the primary-ray code costs about a third of a segment whether one lane needs it or
-// all 64, so rays are made in advance and in batches: it runs once this many of the wave's ray slots have no ray in store (or one
-// has ended its path with none).
-constexpr uint32_t kRegenMinDead = 32;
+// Path regeneration (pt_kernels.hip: REGEN; skybox instantiations): new paths are started once this many ray slots of the wave
+// wait for one.  1 = at once; 64 = only when no ray of the wave is alive, i.e. the passes stay in step.  The crossover is
+// between -MRR 3 and -MRR 5 (profiles/r04_regen_sweep.jsonl): short paths leave few lanes idle and the primary-ray code costs a
+// third of a segment whenever it runs.
+constexpr uint32_t regen_min_dead_for(int mrr) { return mrr >= 5 ? 1u : 64u; }
 
 struct RenderArgs {
     const ClusterDesc *clusters;   // cull hierarchy (pt_scene.hpp: CullTables), read through the scalar cache
@@ -50,7 +51,7 @@ struct RenderArgs {
     int32_t may_leave_envelope;         // 0: no triangle of this scene can be hit outside the envelope, the integrator skips the test
     // A path's last segment (depth + 1 == mrr) can only contribute by hitting an emitter: the statistics-free, skybox-free
     // instantiations search the emitters alone first (CullTables::emis_*) and run the full search only for rays that hit one.
-    uint32_t regen_min_dead;            // skybox instantiations (path regeneration): primary rays are made once this many ray slots of the wave have none in store
+    uint32_t regen_min_dead;            // skybox instantiations (path regeneration): new paths start once this many ray slots of the wave wait for one
     uint32_t last_segment_filter;       // 0 = off
     uint32_t emis_clusters, emis_large_w0, emis_bvh;
 #ifdef PT_BLOCK_PROFILE
@@ -65,6 +66,8 @@ hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves);
 // run: fills narrow, blocks_x and n_tiles
 // (force: 0 = by tile count, 1 = always 8 x 8 tiles, 2 = always the widest: test builds)
 void integrator_plan_tiles(RenderArgs &args, int cu_count, int force = 0);
+// diagnostic: both forms of the box tree's child test on (node, ray, t_best) items; out[2 i] = float form, out[2 i + 1] = half-precision form
+hipError_t launch_box_masks(const BvhNode *d_nodes, const float *d_rays, const float *d_t_best, float err, int n, uint32_t *d_out, hipStream_t stream);
 hipError_t launch_trace_rays(const RenderArgs &args, const float *d_origins, const float *d_directions, int n_rays,
                              int32_t *d_hit_index, float *d_hit_t, hipStream_t stream);
 

@@ -117,7 +117,10 @@ def compare_blocks(acc_a, acc_b, width, height, block, pooled=True, min_pixel_fr
 TOLERANCE = {"z_rms": (0.93, 1.08), "z_mean_abs": 0.05, "rmse_ratio": 1.08, "contributing_z_abs": 5.0,
              # the image binned 8 x 8 and 16 x 16 (compare_blocks): RMSE of the resolved float image, per channel, in units of
              # 1/255 -- at most 1.1 x (1.15 x: a quarter of the bins) what the variances predict AND at most the absolute figure
-             "blocks": {8: {"rmse_ratio": 1.10, "rmse_image_max": 4.0}, 16: {"rmse_ratio": 1.15, "rmse_image_max": 2.0}},
+             # (64-seed fixture, 32 768 samples per pixel: measured 0.98 / 0.99 / 1.10 and 0.51 / 0.48 / 0.61 on the MI355X)
+             "blocks": {8: {"rmse_ratio": 1.10, "rmse_image_max": 1.5}, 16: {"rmse_ratio": 1.15, "rmse_image_max": 0.8}},
+             # the same per PIXEL (compare: rmse_image), in units of 1/255: measured 8.2 / 8.2 / 9.2
+             "rmse_image_pixel_max": 11.0,
              "brightness_z_abs": 3.5}
 
 
@@ -128,6 +131,7 @@ def assert_same_image(r, tol=TOLERANCE):
         assert abs(ch["z_mean"]) < tol["z_mean_abs"], (k, ch)
         assert ch["rmse_mean"] < tol["rmse_ratio"] * ch["rmse_mean_predicted"], (k, ch)
         assert ch["rmse_image"] < tol["rmse_ratio"] * ch["rmse_image_predicted"], (k, ch)
+        assert ch["rmse_image"] < tol["rmse_image_pixel_max"], (k, ch)
     assert abs(r["contributing_z"]) < tol["contributing_z_abs"], r["contributing"]
     assert r["flat_pixels_max_abs_diff"] < 1e-6, r
 

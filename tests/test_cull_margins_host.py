@@ -7,6 +7,7 @@ of the code it bounds, against float64 on the SAME float32 inputs.  CPU only.
     disc_err  = 24 u d_max^2         error of the kernel's |m|^2 - (m.d)^2                                 (pt_kernels.hip: sphere_keep)
     k1, k2                           |t_cull - t_reference| <= (k2 + k1 |t|) / |n.d|                        (cull_reject)
     bvh_err   = 5e-7                 |computed slab t - exact slab t| <= bvh_err (|B| + 255 |A|)            (box_children_kept)
+    half-precision planes            entry plane <= exact <= exit plane in the recentred, scaled T of box_children_kept_h   (-DPT_BOX_F16=1)
     m0, a_max                        a point the reference accepts has every barycentric >= -(m0 + a_max e_t), random walls
 
 u = 2^-24.  Every check reports how much of the bound the worst sample used, so a margin that is merely lucky shows up.
@@ -238,3 +239,70 @@ def test_random_walls_accepted_points_satisfy_the_barycentric_margin():
         checked += int(acc.sum())
     print("barycentric margin: worst accepted sample uses", worst, "of it;", checked, "accepted pairs")
     assert checked > 10000
+
+
+def test_half_precision_planes_bracket_the_exact_ones():
+    """box_children_kept_h (the packed half-precision slab test, -DPT_BOX_F16=1; tests/bvh_emulation.py: planes_f16 restates it
+    operation for operation).  The inequality it stands on: in T = (t - t_enter) S every ENTRY plane it computes lies below the
+    exact plane by at least what any EXIT plane of the same node lies below its exact plane (the exit planes carry no allowance:
+    both sides' errors are charged to the entry planes) -- for planes inside the window that decides, |T| < 2^-10 (beyond it only
+    the order of magnitude matters: DESIGN.md section 5) -- so that exact entry <= exact exit implies computed entry <= computed
+    exit: no child the exact test keeps is dropped.  `exact` is (org + q step - o) / d in float64 on the same float32
+    inputs and t_enter, S are the kernel's own (a shift and a scale common to everything it compares).  Random frames, rays
+    from all around them, with the reciprocal an ulp off either way; reports how much of the entry planes' allowance
+    (float32 stage: 3 err (|B| + 255 |A|) S; two half-precision roundings: 2^-21 (1 + 2^-6)) the worst sample used."""
+    import bvh_emulation as B
+    rng = np.random.default_rng(11)
+    n = 60_000
+    # one synthetic node per item: random origin, a power-of-two step, eight random child boxes
+    org = f32(rng.uniform(-20, 20, (n, 3)))
+    step = f32(2.0 ** rng.integers(-14, -1, n))
+    lo_b = rng.integers(0, 250, (n, 3, 8))
+    hi_b = np.minimum(255, lo_b + rng.integers(0, 120, (n, 3, 8)))
+    t = {"org": org, "step": step, "lo": lo_b.astype(np.uint8), "hi": hi_b.astype(np.uint8), "count": np.full(n, 8), "leaf": np.zeros(n, bool),
+         "base": np.zeros(n, np.uint32)}
+    node = np.arange(n)
+    centre = org.astype(np.float64) + 127.5 * step[:, None].astype(np.float64)
+    # ray origins: inside the frame, near it, far from it; directions: random, some nearly axis-parallel
+    dist = 10.0 ** rng.uniform(-3, 1.6, n) * (rng.random(n) < 0.85)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    o = f32(centre + u * dist[:, None] + rng.normal(size=(n, 3)) * 60 * step[:, None])
+    aim = centre + rng.uniform(-140, 140, (n, 3)) * step[:, None] - o
+    aim[::9, rng.integers(0, 3)] *= 1e-4
+    d = aim / np.linalg.norm(aim, axis=1)[:, None]
+    d = f32(d / np.sqrt((d * d).sum(1))[:, None])
+    used_worst, checked = 0.0, 0
+    for ulp in (-1, 0, 1):
+        # the kernel's reciprocal is v_rcp_f32, an ulp off at worst: emulate by perturbing the direction so that 1/d moves an ulp
+        dd = d if ulp == 0 else np.nextafter(d, np.where((ulp > 0) == (d > 0), 0, np.sign(d) * np.inf).astype(np.float32))
+        p = B.planes_f16(t, node, o, dd)
+        ok = ~p["bad"] & np.isfinite(p["t_enter"])
+        te, S = p["t_enter"].astype(np.float64)[:, None, None], p["s"].astype(np.float64)[:, None, None]
+        inv64 = 1.0 / d.astype(np.float64)          # the EXACT ray: the unperturbed direction
+        neg = (inv64 < 0)[:, :, None]
+        near_q = np.where(neg, hi_b, lo_b).astype(np.float64)
+        far_q = np.where(neg, lo_b, hi_b).astype(np.float64)
+        base = (org.astype(np.float64) - o.astype(np.float64))[:, :, None]
+        exact_n = ((base + near_q * step[:, None, None].astype(np.float64)) * inv64[:, :, None] - te) * S
+        exact_f = ((base + far_q * step[:, None, None].astype(np.float64)) * inv64[:, :, None] - te) * S
+        tn, tf = p["tn"].astype(np.float64), p["tf"].astype(np.float64)
+        win = 2.0 ** -10
+        same_sign = (np.sign(dd) == np.sign(d)).all(1) & ok      # (an ulp step across zero would turn the ray around)
+        sel_n = same_sign[:, None, None] & (np.abs(exact_n) < win) & np.isfinite(tn)
+        sel_f = same_sign[:, None, None] & (np.abs(exact_f) < win) & np.isfinite(tf)
+        # per item (one ray, one node): the least slack of an entry plane covers the worst undershoot of an exit plane -- the exit
+        # planes carry no allowance of their own, both sides' errors are charged to the entry planes once per node
+        big = 1e30
+        slack_n = np.where(sel_n, exact_n - tn, big).min((1, 2))
+        under_f = np.where(sel_f, exact_f - tf, -big).max((1, 2))
+        has = (slack_n < big) & (under_f > -big)
+        assert (slack_n[slack_n < big] >= 0).all(), float(slack_n.min())
+        assert (slack_n[has] >= np.maximum(under_f[has], 0)).all(), float((under_f[has] - slack_n[has]).max())
+        # share of the allowance used: what the entry planes would overshoot without it + what the exit planes undershoot
+        m_t = p["m_t"].astype(np.float64)
+        over_n = np.where(sel_n, tn + m_t[:, None, None] - exact_n, -big).max((1, 2))
+        used = (np.maximum(over_n[has], 0) + np.maximum(under_f[has], 0)) / m_t[has]
+        used_worst = max(used_worst, float(used.max()))
+        checked += int(sel_n.sum() + sel_f.sum())
+    print("half-precision planes:", checked, "planes inside the window; worst entry plane uses", used_worst, "of the allowance")
+    assert checked > 1_000_000 and used_worst < 1.0

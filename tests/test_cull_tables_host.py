@@ -285,6 +285,9 @@ def test_box_tree_never_drops_the_chain_above_a_hit(tmp_path, bvh_mode, request)
     while len(node):
         kept = B.children_kept(t, node, ro, rd, tb, 5e-7)
         assert kept[np.arange(len(node)), child].all(), f"a node of level {levels} above a hit was dropped"
+        # the packed half-precision form of the test (pt_kernels.hip: box_children_kept_h, built with -DPT_BOX_F16=1) on the same items
+        kept_h = B.children_kept_f16(t, node, ro, rd, tb)
+        assert kept_h[np.arange(len(node)), child].all(), f"half precision: a node of level {levels} above a hit was dropped"
         child, node = pos[node], par[node]
         live = node >= 0
         node, child, ro, rd, tb = node[live], child[live], ro[live], rd[live], tb[live]

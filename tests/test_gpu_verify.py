@@ -160,3 +160,35 @@ def test_smallest_queues_on_a_deep_tree_of_nested_triangles(tmp_path):
         assert st["verify_checked"] == st["segments"] > 480 * 270 * 4 and st["verify_mismatches"] == 0, (cap, st)
         assert st["partial_commit_rounds"] > 10000, st
         assert _digest(s, s2, c) == shipped, cap
+
+
+def test_both_forms_of_the_box_test_keep_what_the_exact_test_keeps():
+    """pt_kernels.hip has the box tree's child test twice: in float32 (box_children_kept, what ships) and in packed half precision
+    (box_children_kept_h, -DPT_BOX_F16=1: built, verified and measured in round 4 -- 3.4 % slower, profiles/r04_ab_logs.txt slab16
+    -- and kept as a compile-time variant).  The test build runs BOTH on 200 000 random (node, ray, t_best) items
+    (tools/box_mask_probe.py: frames of every size, origins inside, near and far, nearly and exactly axis-parallel rays): neither
+    may drop a child the exact float64 test keeps, and each agrees with its numpy restatement (tests/bvh_emulation.py) except where
+    v_rcp_f32's last bit decides."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import box_mask_probe as P
+    import bvh_emulation as B
+    n = 200_000
+    raw, o, d, t_best = P.items(n)
+    L = pt.load_library(os.path.join(os.path.dirname(pt.LIB_PATH), "libpt_testhooks.so"))
+    L.pt_test_box_masks.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int32, C.POINTER(C.c_uint32)]
+    rays = np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
+    out = np.zeros(2 * n, np.uint32)
+    assert L.pt_test_box_masks(raw.ctypes.data_as(C.c_void_p), rays.ctypes.data_as(C.POINTER(C.c_float)), t_best.ctypes.data_as(C.POINTER(C.c_float)),
+                               C.c_float(5e-7), n, out.ctypes.data_as(C.POINTER(C.c_uint32))) == 0, L.pt_last_error()
+    bits = lambda m: ((m[:, None] >> np.arange(8)[None, :]) & 1).astype(bool)
+    dev32, dev16 = bits(out[0::2]), bits(out[1::2])
+    t = B.decode(raw)
+    ex = P.exact_keep(t, o, d, t_best)
+    assert ex.sum() > 20000
+    assert not (ex & ~dev32).any() and not (ex & ~dev16).any()
+    node = np.arange(n)
+    assert (dev32 != B.children_kept(t, node, o, d, t_best, 5e-7)).any(1).mean() < 0.05
+    assert (dev16 != B.children_kept_f16(t, node, o, d, t_best)).any(1).mean() < 0.02
+    # how loose: the half-precision form keeps a little more than the float form, both far less than everything
+    assert dev32.sum() <= dev16.sum() < 1.25 * dev32.sum()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every segment of the full-size frames against the reference's all-triangles loop, beyond what the test suite runs:
 
-    python tools/verify_full.py [shipped] [only=<part of a frame's name>]   ->  one line per frame (segments checked, mismatches, seconds)
+    python tools/verify_full.py [shipped] [lib=<name>] [only=<part of a frame's name>]   ->  one line per frame (segments checked, mismatches, seconds)
 
 Without an argument: libpt_verify.so (the statistics instantiations, full search on every segment).  `shipped`:
 libpt_verify_shipped.so -- the statistics-free instantiations a caller without pt_render_stats gets (two pixels per lane,
@@ -20,7 +20,9 @@ import make_replicated_scene as M
 
 pt = importlib.import_module("path-tracing_amd")
 shipped = len(sys.argv) > 1 and sys.argv[1] == "shipped"
-L = pt.load_library(os.path.join(ROOT, "path-tracing_amd", "lib", "libpt_verify_shipped.so") if shipped else pt.VERIFY_LIB_PATH)
+named = [a[4:] for a in sys.argv[1:] if a.startswith("lib=")]      # lib=<name>: path-tracing_amd/lib/libpt_<name>.so (make verify-variant NAME=...)
+L = pt.load_library(os.path.join(ROOT, "path-tracing_amd", "lib", f"libpt_{named[0]}.so") if named else
+                    os.path.join(ROOT, "path-tracing_amd", "lib", "libpt_verify_shipped.so") if shipped else pt.VERIFY_LIB_PATH)
 L.pt_test_set_mutation(b"reset", 0.0)
 models = os.path.join(ROOT, "models") + "/"
 jobs = [("configs[2] Tor.obj 1920x1080x1024spp", models, "Tor.obj", 1920, 1080, 1024, -1.0),
