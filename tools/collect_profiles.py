@@ -72,20 +72,29 @@ def phase_shares(path, names):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r03")
+    ap.add_argument("--tag", default="r04")
     a = ap.parse_args()
     t = a.tag
     G = os.path.join(ROOT, "gpurun_out", t)
     os.makedirs(P, exist_ok=True)
     shutil.copy(os.path.join(G, "bench_1gpu.json"), os.path.join(P, f"{t}_bench_1gpu.json"))
     shutil.copy(os.path.join(G, "pmc_hbm.json"), os.path.join(P, f"{t}_pmc_hbm.json"))
+    if os.path.exists(os.path.join(G, "pmc_hbm_c2_pmc_hbm.json")):      # BASELINE configs[2]: the counters of the 1024-spp launch
+        shutil.copy(os.path.join(G, "pmc_hbm_c2_pmc_hbm.json"), os.path.join(P, f"{t}_c2_pmc_hbm.json"))
+    for name in ("open_scene_probe.jsonl", "t_sweep.jsonl"):
+        if os.path.exists(os.path.join(G, name)) and os.path.getsize(os.path.join(G, name)) > 0:
+            shutil.copy(os.path.join(G, name), os.path.join(P, f"{t}_{name}"))
+    sky = glob.glob(os.path.join(G, "kt_sky", "**", "*kernel_stats.csv"), recursive=True)
+    if sky:
+        shutil.copy(max(sky, key=os.path.getmtime), os.path.join(P, f"{t}_sky_kernel_stats.csv"))
     shutil.copy(os.path.join(G, "configs.jsonl"), os.path.join(P, f"{t}_configs_one_gpu.jsonl"))
     shutil.copy(os.path.join(G, "mutation_sweep.jsonl"), os.path.join(P, f"{t}_mutation_sweep.jsonl"))
     ks = max(glob.glob(os.path.join(G, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(ks, os.path.join(P, f"{t}_kernel_stats.csv"))
     out = {}
     for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,false,false,false,false,false>)", True),
-                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,true,false,false,false,false>)", True)):
+                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,true,false,false,false,false>)", True),
+                               ("pmc_sky", "Tor.obj without its back wall under a sky bitmap, 1920x1080x256spp (pt_render -SKYBOX -BENCH_STEPS 1, timed kernel integrate_kernel<true,false,false,false,false,false>, path regeneration)", True)):
         m = detail(os.path.join(G, name), timed)
         if m:
             out[label] = m
