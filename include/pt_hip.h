@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 typedef enum pt_status {
     PT_OK = 0,

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "lib", "libpt_hip
 PT_OK = 0
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT_ERR_PARSE", 4: "PT_ERR_NO_DEVICE",
                 5: "PT_ERR_HIP", 6: "PT_ERR_OUT_OF_MEMORY", 7: "PT_ERR_UNSUPPORTED"}
-PT_ABI_VERSION = 3
+PT_ABI_VERSION = 4
 RNG_COUNTER, RNG_REFERENCE_STREAM = 0, 1
 # test-only builds of the same ABI (csrc/Makefile): never loaded by the product path
 VERIFY_LIB_PATH = os.path.join(_HERE, "lib", "libpt_verify.so")

@@ -242,10 +242,13 @@ def test_tiny_and_empty_scenes(tmp_path):
         assert st["contributing"] > 0
 
 
-def test_node_stack_overflow_paths(tmp_path):
+def test_node_stack_overflow_paths(tmp_path, hooks_lib, request):
     """1 800 small triangles packed into a ball of radius 1: every ray through it passes nearly every sphere of the
     tree, so a walk round produces far more children than the 96-entry node stack and the 144-entry pair queue of the
-    small-scene kernel hold -- the partial-commit and forced-commit paths run, and must not change any result."""
+    small-scene kernel hold -- the partial-commit and forced-commit paths run, and must not change any result.
+    (1 800 triangles are beyond the shipped small / big switch since round 4: the test hook keeps them on the sphere-tree path.)"""
+    hooks_lib.pt_test_set_mutation(b"big_threshold", 16384.0)
+    request.addfinalizer(lambda: hooks_lib.pt_test_set_mutation(b"reset", 0.0))
     rng = np.random.default_rng(99)
     d = str(tmp_path) + "/"
     open(d + "m.mtl", "w").write("newmtl 0\nKe 1 1 1\nKd 1 1 1\nnewmtl 1\nNs 100\nKs 0.9 0.9 0.9\nKd 0.7 0.7 0.7\n")
@@ -258,7 +261,7 @@ def test_node_stack_overflow_paths(tmp_path):
                   f"f {nv+1} {nv+2} {nv+3}"]
         nv += 3
     open(d + "ball.obj", "w").write("\n".join(lines) + "\n")
-    g = pt.Scene.load_obj(d, "ball.obj", device=0)
+    g = pt.Scene.load_obj(d, "ball.obj", device=0, library=hooks_lib)
     o = O.Scene.load(d, "ball.obj")
     t = g.cull_tables()
     assert list(t["kind"]) == [0] and t["n_levels"][0] == 4           # one small-triangle cluster, 1800 -> 225 -> 29 -> 4
