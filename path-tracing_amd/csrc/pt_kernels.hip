@@ -73,11 +73,20 @@ struct SmallQueues2 { static constexpr int kNodeStack = PT_SMALL2_NODES, kPairQu
 #ifndef PT_BIG_EXACT_AT
 #define PT_BIG_EXACT_AT 64    // big scenes: pre-filtered pairs waiting before an exact round runs (fewer = earlier pruning, emptier rounds)
 #endif
+#ifndef PT_BOX_SCHED
+#define PT_BOX_SCHED 1        // box tree's child test: a scheduling barrier after every PT_BOX_SCHED children (9 = none)
+#endif
 #ifndef PT_BOX_SPREAD
 #define PT_BOX_SPREAD 0       // 1: under-filled box-tree rounds spread a node's children over 2 / 4 / 8 lanes (measured: +-0 on the x64
 #endif                        // replica, -1 % on x195 -- the tail rounds wait for their node loads, not for issue slots; ab62)
 #ifndef PT_BIG_WAVES
-#define PT_BIG_WAVES (PT_WAVES_PER_SIMD - 2)   // waves per SIMD the big-scene and skybox instantiations are compiled for
+#define PT_BIG_WAVES (PT_WAVES_PER_SIMD - 2)   // waves per SIMD the big-scene instantiations are compiled for (they fit 6: 77 VGPRs)
+#endif
+#ifndef PT_SKY_WAVES
+// ... and the skybox instantiations: 5 since round 4 (96 VGPRs, no scratch; at 4 the compiler took 102-117): +9.6 % on the open
+// scenes (Tor.obj without its back wall 6 950 -> 7 620 Msamples/s at 64 spp, the torus x9 3 585 -> 3 915; r04_ab_logs.txt sky5).
+// At 6 (80 VGPRs) the lookup's double arithmetic spills 30 registers.
+#define PT_SKY_WAVES (PT_WAVES_PER_SIMD - 1)
 #endif
 struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };
 
@@ -289,8 +298,17 @@ __device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, 
     const float f2x = px - r3.x, f2y = py - r3.y, f2z = pz - r3.z;
     const float sq = r1.w;
     const float q1 = area2_of(f0x, f0y, f0z, f1x, f1y, f1z);
+#ifdef PT_EXACT_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const float q2 = area2_of(f0x, f0y, f0z, f2x, f2y, f2z);
+#ifdef PT_EXACT_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const float q3 = area2_of(f2x, f2y, f2z, f1x, f1y, f1z);
+#ifdef PT_EXACT_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     float s1, s2, s3;
     // one range check for the three roots: min and max of the squared areas decide for all of them
     if (__all(fast_fp_ok(__builtin_fminf(__builtin_fminf(q1, q2), q3)) & fast_fp_ok(__builtin_fmaxf(__builtin_fmaxf(q1, q2), q3)))) {
@@ -508,6 +526,9 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
         nz0 = (up ? nz1 : nz0) >> sh; fz0 = (up ? fz1 : fz0) >> sh;
     }
     uint32_t m = 0;
+#ifdef PT_BOX_SCHED_SETUP
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
         const int k = c & 3;
@@ -515,11 +536,97 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
         const float tnx = __builtin_fmaf(ax, byte_to_float(up ? nx1 : nx0, k), nbx), tfx = __builtin_fmaf(ax, byte_to_float(up ? fx1 : fx0, k), bx);
         const float tny = __builtin_fmaf(ay, byte_to_float(up ? ny1 : ny0, k), nby), tfy = __builtin_fmaf(ay, byte_to_float(up ? fy1 : fy0, k), by);
         const float tnz = __builtin_fmaf(az, byte_to_float(up ? nz1 : nz0, k), nbz), tfz = __builtin_fmaf(az, byte_to_float(up ? fz1 : fz0, k), bz);
+#ifdef PT_BOX_SCHED_MID
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         const float t_in = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, t_min));
         const float t_out = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, t_best));
         m |= !(t_in > t_out) ? (1u << c) : 0u;   // a NaN keeps
+        // One child at a time.  Left alone, the compiler interleaves the eight children's conversions, multiply-adds and
+        // comparisons into one long schedule; a scheduling barrier after every child -- the same instructions, 222 per node visit,
+        // the same registers -- makes the x64 / x195 replicas 3.8 % / 2.9 % faster (2 152 -> 2 234, 1 447 -> 1 492 Msamples/s;
+        // after 2 or 4 children: +0.9 % / 0; r04_ab_logs.txt sched).  Nothing else in the kernels reacted to such barriers.
+        if ((c + 1) % PT_BOX_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (PER < 8) m <<= sub * PER;
+    return m;
+}
+
+#ifndef PT_MIX_SCHED
+#define PT_MIX_SCHED 1
+#endif
+#ifndef PT_BOX_MIX
+#define PT_BOX_MIX 0   // 1: the float test with the byte -> float conversion folded into the multiply-add (box_children_kept_mix)
+#endif
+// ---------------------------------------------------------------------------------------------------------------
+// The float test again, bit for bit -- with the conversions gone (round 4; profiles/r04_ab_logs.txt slabmix).  A plane byte q,
+// zero-extended to 16 bits, is the half-precision subnormal q 2^-24; v_fma_mix_f32 takes one operand as a half, widens it exactly
+// and does the fused multiply-add in float32.  With A 2^24 for coefficient (folded into the step's exponent) the product is the
+// same real number A q, the sum and its single rounding the same: fma(A 2^24, q 2^-24, B) == fma(A, float(q), B) for every input.
+// So the masks, the rounds, the frames and every argument of DESIGN.md section 5 are those of box_children_kept; what changes is
+// the instruction count: per child six v_fma_mix_f32 instead of six v_cvt_f32_ubyteN + six v_fma_f32, and per node 24
+// instructions that unpack the bytes of the twelve row words into halves (one unpacked register serves two children).
+// ---------------------------------------------------------------------------------------------------------------
+// (Written as inline assembly on purpose.  Left to the compiler -- __builtin_fmaf(a, float(half), b) selects the same
+// v_fma_mix_f32, 203 instructions per node visit instead of 218 with the waits it puts around inline assembly -- the kernel is
+// 2.5 % SLOWER than the float test on the x64 replica instead of 0.8 % faster: its scheduler hoists all twelve unpackings and
+// lengthens the dependent stretch of a visit; r04_ab_logs.txt slabmix.)
+template <int HI>
+__device__ __forceinline__ float fma_mix_h(float a, uint32_t q2, float b) {   // a * half(q2.lo or q2.hi) + b, one rounding, float32
+    float d;
+    if constexpr (HI == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(q2), "v"(b));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(q2), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t box_children_kept_mix(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 q3, const Ray &r,
+                                                          float ix, float iy, float iz, float t_best, float err) {
+    // the coefficients times 2^24: the factor goes into the step's exponent (pt_scene.cpp keeps it at or below 2^100), everything
+    // derived from them scales back by an exact power of two, so e2 and the planes are those of box_children_kept bit for bit
+    const float step24 = __uint_as_float(((q0.w & 0xFFu) + 24u) << 23);
+    const float cx = step24 * ix, cy = step24 * iy, cz = step24 * iz;
+    const float bx = (__uint_as_float(q0.x) - r.ox) * ix, by = (__uint_as_float(q0.y) - r.oy) * iy, bz = (__uint_as_float(q0.z) - r.oz) * iz;
+    const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(bx), __builtin_fabsf(by)), __builtin_fabsf(bz));
+    const float cmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cx), __builtin_fabsf(cy)), __builtin_fabsf(cz));
+    const float e2 = 2.0f * err * __builtin_fmaf(255.0f * 5.9604644775390625e-08f, cmax, bmax);   // 255 |A|max + |B|max
+    const float nbx = bx - e2, nby = by - e2, nbz = bz - e2, t_min = -e2;
+    const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
+    const uint32_t nx[2] = {sx ? q2.z : q1.x, sx ? q2.w : q1.y}, fx[2] = {sx ? q1.x : q2.z, sx ? q1.y : q2.w};
+    const uint32_t ny[2] = {sy ? q3.x : q1.z, sy ? q3.y : q1.w}, fy[2] = {sy ? q1.z : q3.x, sy ? q1.w : q3.y};
+    const uint32_t nz[2] = {sz ? q3.z : q2.x, sz ? q3.w : q2.y}, fz[2] = {sz ? q2.x : q3.z, sz ? q2.y : q3.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            // bytes (0, 2) or (1, 3) of a row word as two 16-bit numbers: children 4 w + par and 4 w + par + 2
+            auto un = [&](uint32_t v) {
+                if (par == 0) return v & 0x00FF00FFu;
+                uint32_t d;
+                asm("v_pk_lshrrev_b16 %0, 8, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(v));   // (op_sel_hi: the inline 8 shifts the high half too)
+                return d;
+            };
+            const uint32_t unx = un(nx[w]), uny = un(ny[w]), unz = un(nz[w]), ufx = un(fx[w]), ufy = un(fy[w]), ufz = un(fz[w]);
+            auto child = [&](auto hi_c) {
+                constexpr int HI = decltype(hi_c)::value;
+                const float tnx = fma_mix_h<HI>(cx, unx, nbx), tfx = fma_mix_h<HI>(cx, ufx, bx);
+                const float tny = fma_mix_h<HI>(cy, uny, nby), tfy = fma_mix_h<HI>(cy, ufy, by);
+                const float tnz = fma_mix_h<HI>(cz, unz, nbz), tfz = fma_mix_h<HI>(cz, ufz, bz);
+                // (max / min by name: on the outputs of inline assembly the compiler would first quiet possible signalling NaNs,
+                // one v_max_f32 x, x per value)
+                float t_in, t_out;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t_in) : "v"(tnx), "v"(tny), "v"(tnz));
+                asm("v_max_f32 %0, %1, %2" : "=v"(t_in) : "v"(t_in), "v"(t_min));
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t_out) : "v"(tfx), "v"(tfy), "v"(tfz));
+                asm("v_min_f32 %0, %1, %2" : "=v"(t_out) : "v"(t_out), "v"(t_best));
+                m |= !(t_in > t_out) ? (1u << (4 * w + par + 2 * HI)) : 0u;   // a NaN keeps
+            };
+            child(std::integral_constant<int, 0>());
+            if (PT_MIX_SCHED == 3) __builtin_amdgcn_sched_barrier(0);
+            child(std::integral_constant<int, 1>());
+            // one pair of children at a time: the unpacked rows of all four would cost a wave per SIMD
+            if (PT_MIX_SCHED == 1 || PT_MIX_SCHED == 3 || (PT_MIX_SCHED == 2 && par == 1)) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     return m;
 }
 
@@ -730,6 +837,9 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
                     const float4 *rp = reinterpret_cast<const float4 *>(a.bary_all + tri);
                     const float4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
+#ifdef PT_PREFILTER_SCHED
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                     CullRec rec;
                     rec.n[0] = c0.x; rec.n[1] = c0.y; rec.n[2] = c0.z; rec.w = c0.w;
                     rec.au[0] = c1.x; rec.au[1] = c1.y; rec.au[2] = c1.z; rec.cu = c1.w;
@@ -1040,6 +1150,9 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                                 const uint32_t c = sub + (static_cast<uint32_t>(i) << shift);   // interleaved: the item's lanes read consecutive records
                                 const float4 sp = cs[c];
                                 m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << c) : 0u;
+#ifdef PT_SPHERE_SCHED
+                                if ((i + 1) % PT_SPHERE_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
                             }
                         };
                         if (shift == 0u) test(std::integral_constant<int, 8>());
@@ -1110,8 +1223,12 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 auto quad = [&](uint32_t k0) {
                     const CullRec rec = load_cull(bp + 12 * k0);
 #pragma unroll
-                    for (int k = 0; k < R; ++k)
+                    for (int k = 0; k < R; ++k) {
                         if (PT_SLOT_ON(k)) m[k] |= (~cull_reject_quad(rec, q[k], k1, k2, a_max, m0q, t_guard) & 3u) << k0;
+#ifdef PT_WALL_SCHED_RAY
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                    }
                 };
                 auto single = [&](uint32_t slot) {
                     const CullRec rec = load_cull(bp + 12 * slot);
@@ -1154,7 +1271,12 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                             }
                         }
                     } else {
-                        for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) quad(k0);
+                        for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {
+                            quad(k0);
+#ifdef PT_WALL_SCHED
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                        }
                     }
                 } else
                 for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {   // records are padded to whole words
@@ -1230,9 +1352,15 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     const float ix = lds.rinv.v[0][src], iy = lds.rinv.v[1][src], iz = lds.rinv.v[2][src];
+#ifdef PT_BOX_SCHED_LOADS
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
 #if PT_BOX_F16
                     static_assert(!PT_BOX_SPREAD, "the half-precision test handles a node's eight children in one lane");
                     if (shift == 0u) m8 = box_children_kept_h(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err);
+#elif PT_BOX_MIX
+                    static_assert(!PT_BOX_SPREAD, "the mixed-precision form handles a node's eight children in one lane");
+                    if (shift == 0u) m8 = box_children_kept_mix(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err);
 #else
                     if (shift == 0u) m8 = box_children_kept<8>(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err);
 #endif
@@ -1243,6 +1371,9 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     leaf = ((q0.w >> 11) & 1u) != 0u;                       // BvhNode::meta
                     base = leaf ? (q0.w >> 12) * kFan : (q0.w >> 12);      // a leaf's first slot / an inner node's first child
                 }
+#ifdef PT_BOX_SCHED_AFTER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 kids = __builtin_popcount(m8);
                 keep = cnt;
                 // Children of inner nodes go back on the stack, triangles of leaves into the pair queue.  One prefix sum serves both
@@ -1361,7 +1492,7 @@ constexpr int rays_per_lane() { return (!SKY && !STATS) ? (BIG ? PT_BIG_RAYS_PER
 // fill the chip with 16 x 8 tiles (small previews, thin row bands) -- half as many waves would leave wave slots empty.
 // ADAPT = the two-pixel kernel for launches with adaptive sampling on (error >= 0): see "Compaction" in the pass loop.
 template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW = false, bool ADAPT = false>
-__global__ __launch_bounds__(kBlock, (SKY || BIG) ? PT_BIG_WAVES : (STATS || (!NARROW && rays_per_lane<SKY, BIG, STATS>() > 1)) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES /* (that one spills at 5) */ : PT_SKY_WAVES) : BIG ? PT_BIG_WAVES : (STATS || (!NARROW && rays_per_lane<SKY, BIG, STATS>() > 1)) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
     static_assert(!NARROW || (!SKY && !STATS), "only the statistics-free, skybox-free kernels have a narrow variant");
     constexpr int R = NARROW ? 1 : rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
     static_assert(!ADAPT || (R == 2 && !BIG), "compaction moves a lane's second pixel into another lane's free first slot");
@@ -2101,7 +2232,9 @@ __global__ __launch_bounds__(kBlock) void box_masks_kernel(const BvhNode *__rest
     const float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
     const uint32_t exists = (2u << ((q0.w >> 8) & 7u)) - 1u;
     out[2 * i] = box_children_kept<8>(q0, q1, q2, q3, r, ix, iy, iz, t_best[i], err) & exists;
-    out[2 * i + 1] = box_children_kept_h(q0, q1, q2, q3, r, ix, iy, iz, t_best[i], err) & exists;
+    // (bits 8-15 of the second word: the mixed-precision form, which must equal the float form bit for bit)
+    out[2 * i + 1] = (box_children_kept_h(q0, q1, q2, q3, r, ix, iy, iz, t_best[i], err) & exists) |
+                     ((box_children_kept_mix(q0, q1, q2, q3, r, ix, iy, iz, t_best[i], err) & exists) << 8);
 }
 hipError_t launch_box_masks(const BvhNode *d_nodes, const float *d_rays, const float *d_t_best, float err, int n, uint32_t *d_out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

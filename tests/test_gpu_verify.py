@@ -182,11 +182,12 @@ def test_both_forms_of_the_box_test_keep_what_the_exact_test_keeps():
     assert L.pt_test_box_masks(raw.ctypes.data_as(C.c_void_p), rays.ctypes.data_as(C.POINTER(C.c_float)), t_best.ctypes.data_as(C.POINTER(C.c_float)),
                                C.c_float(5e-7), n, out.ctypes.data_as(C.POINTER(C.c_uint32))) == 0, L.pt_last_error()
     bits = lambda m: ((m[:, None] >> np.arange(8)[None, :]) & 1).astype(bool)
-    dev32, dev16 = bits(out[0::2]), bits(out[1::2])
+    dev32, dev16, devmix = bits(out[0::2]), bits(out[1::2] & 0xFF), bits(out[1::2] >> 8)
     t = B.decode(raw)
     ex = P.exact_keep(t, o, d, t_best)
     assert ex.sum() > 20000
     assert not (ex & ~dev32).any() and not (ex & ~dev16).any()
+    assert np.array_equal(devmix, dev32)            # box_children_kept_mix: the same arithmetic, so the same masks, always
     node = np.arange(n)
     assert (dev32 != B.children_kept(t, node, o, d, t_best, 5e-7)).any(1).mean() < 0.05
     assert (dev16 != B.children_kept_f16(t, node, o, d, t_best)).any(1).mean() < 0.02

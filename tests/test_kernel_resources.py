@@ -39,6 +39,8 @@ HOT = {
     "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb1EEEvNS_10RenderArgsE": ("the same with adaptive sampling on (compacts sparse passes)", 5, 8192),
     "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb1ELb0EEEvNS_10RenderArgsE": ("small scenes, one pixel per lane (small launches)", 6, 6826),
     "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 6, 6826),
+    "_ZN2pt16integrate_kernelILb1ELb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("small scenes under a skybox (path regeneration)", 5, 8192),
+    "_ZN2pt16integrate_kernelILb1ELb1ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes under a skybox", 5, 8192),
 }
 
 

@@ -70,7 +70,7 @@ def main():
                              C.c_float(5e-7), n, out.ctypes.data_as(C.POINTER(C.c_uint32)))
     assert rc == 0, L.pt_last_error()
     bits = lambda m: ((m[:, None] >> np.arange(8)[None, :]) & 1).astype(bool)
-    dev32, dev16 = bits(out[0::2]), bits(out[1::2])
+    dev32, dev16, devmix = bits(out[0::2]), bits(out[1::2] & 0xFF), bits(out[1::2] >> 8)
     t = B.decode(raw)
     node = np.arange(n)
     em32 = B.children_kept(t, node, o, d, t_best, 5e-7)
@@ -79,10 +79,11 @@ def main():
     print(f"{n} items; kept children per item: exact {ex.sum(1).mean():.3f}  float (device) {dev32.sum(1).mean():.3f}  half (device) {dev16.sum(1).mean():.3f}  "
           f"float (numpy) {em32.sum(1).mean():.3f}  half (numpy) {em16.sum(1).mean():.3f}")
     print("device float drops a child the exact test keeps:", int((ex & ~dev32).sum()), " device half:", int((ex & ~dev16).sum()))
+    print("mixed-precision form (v_fma_mix_f32) differs from the float form in", int((devmix != dev32).any(1).sum()), "items (must be 0)")
     print("device vs numpy, items that differ: float", int((dev32 != em32).any(1).sum()), " half", int((dev16 != em16).any(1).sum()))
     for c in range(8):
         print(f"  child {c}: half device keeps {dev16[:, c].mean():.3f}, numpy {em16[:, c].mean():.3f}, exact {ex[:, c].mean():.3f}, wrongly dropped {int((ex[:, c] & ~dev16[:, c]).sum())}")
-    return 0 if (ex & ~dev16).sum() == 0 and (ex & ~dev32).sum() == 0 else 1
+    return 0 if (ex & ~dev16).sum() == 0 and (ex & ~dev32).sum() == 0 and (devmix == dev32).all() else 1
 
 
 if __name__ == "__main__":

@@ -33,11 +33,20 @@ d = tempfile.mkdtemp() + "/"
 for n, spp in ((64, 32), (195, 16)):
     M.generate(os.path.join(ROOT, "models"), d, f"x{n}.obj", n)
     jobs.append((f"configs[4] x{n} replica 1920x1080x{spp}spp", d, f"x{n}.obj", 1920, 1080, spp, -1.0))
+# an open scene under a sky: the skybox instantiations (path regeneration; the torus x9 likewise for the box tree)
+import make_open_scene as MO
+MO.generate(os.path.join(ROOT, "models"), d)
+M.generate(os.path.join(ROOT, "models"), d, "x9.obj", 9)
+MO.generate(os.path.join(ROOT, "models"), d, name="X9Open.obj", source="x9.obj", source_dir=d)
+jobs.append(("open Tor.obj + skybox 1920x1080x128spp", d, "TorOpen.obj", 1920, 1080, 128, -1.0))
+jobs.append(("open x9 + skybox 1920x1080x64spp -ERR 0.001", d, "X9Open.obj", 1920, 1080, 64, 0.001))
 only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
 for name, dd, obj, W, H, spp, err in jobs:
     if only and not any(o in name for o in only):
         continue
     s = pt.Scene.load_obj(dd, obj, device=0, library=L)
+    if "skybox" in name:
+        s.set_skybox(d + "sky.bmp")
     t = time.perf_counter()
     st = s.render_host(W, H, spp, 8, error=err)[3]
     extra = f", {st['partial_commit_rounds']} compacted tile-passes" if shipped and err >= 0 else ""
