@@ -298,17 +298,8 @@ __device__ __forceinline__ float exact_inside(const ExactRec *__restrict__ rec, 
     const float f2x = px - r3.x, f2y = py - r3.y, f2z = pz - r3.z;
     const float sq = r1.w;
     const float q1 = area2_of(f0x, f0y, f0z, f1x, f1y, f1z);
-#ifdef PT_EXACT_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     const float q2 = area2_of(f0x, f0y, f0z, f2x, f2y, f2z);
-#ifdef PT_EXACT_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     const float q3 = area2_of(f2x, f2y, f2z, f1x, f1y, f1z);
-#ifdef PT_EXACT_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     float s1, s2, s3;
     // one range check for the three roots: min and max of the squared areas decide for all of them
     if (__all(fast_fp_ok(__builtin_fminf(__builtin_fminf(q1, q2), q3)) & fast_fp_ok(__builtin_fmaxf(__builtin_fmaxf(q1, q2), q3)))) {
@@ -526,9 +517,6 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
         nz0 = (up ? nz1 : nz0) >> sh; fz0 = (up ? fz1 : fz0) >> sh;
     }
     uint32_t m = 0;
-#ifdef PT_BOX_SCHED_SETUP
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
         const int k = c & 3;
@@ -536,9 +524,6 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
         const float tnx = __builtin_fmaf(ax, byte_to_float(up ? nx1 : nx0, k), nbx), tfx = __builtin_fmaf(ax, byte_to_float(up ? fx1 : fx0, k), bx);
         const float tny = __builtin_fmaf(ay, byte_to_float(up ? ny1 : ny0, k), nby), tfy = __builtin_fmaf(ay, byte_to_float(up ? fy1 : fy0, k), by);
         const float tnz = __builtin_fmaf(az, byte_to_float(up ? nz1 : nz0, k), nbz), tfz = __builtin_fmaf(az, byte_to_float(up ? fz1 : fz0, k), bz);
-#ifdef PT_BOX_SCHED_MID
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         const float t_in = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, t_min));
         const float t_out = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, t_best));
         m |= !(t_in > t_out) ? (1u << c) : 0u;   // a NaN keeps
@@ -552,9 +537,6 @@ __device__ __forceinline__ uint32_t box_children_kept(const uint4 q0, const uint
     return m;
 }
 
-#ifndef PT_MIX_SCHED
-#define PT_MIX_SCHED 1
-#endif
 #ifndef PT_BOX_MIX
 #define PT_BOX_MIX 0   // 1: the float test with the byte -> float conversion folded into the multiply-add (box_children_kept_mix)
 #endif
@@ -621,10 +603,9 @@ __device__ __forceinline__ uint32_t box_children_kept_mix(const uint4 q0, const 
                 m |= !(t_in > t_out) ? (1u << (4 * w + par + 2 * HI)) : 0u;   // a NaN keeps
             };
             child(std::integral_constant<int, 0>());
-            if (PT_MIX_SCHED == 3) __builtin_amdgcn_sched_barrier(0);
             child(std::integral_constant<int, 1>());
             // one pair of children at a time: the unpacked rows of all four would cost a wave per SIMD
-            if (PT_MIX_SCHED == 1 || PT_MIX_SCHED == 3 || (PT_MIX_SCHED == 2 && par == 1)) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     return m;
@@ -837,9 +818,6 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     r.dx = lds.ray[3][src]; r.dy = lds.ray[4][src]; r.dz = lds.ray[5][src];
                     const float4 *rp = reinterpret_cast<const float4 *>(a.bary_all + tri);
                     const float4 c0 = rp[0], c1 = rp[1], c2 = rp[2];
-#ifdef PT_PREFILTER_SCHED
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
                     CullRec rec;
                     rec.n[0] = c0.x; rec.n[1] = c0.y; rec.n[2] = c0.z; rec.w = c0.w;
                     rec.au[0] = c1.x; rec.au[1] = c1.y; rec.au[2] = c1.z; rec.cu = c1.w;
@@ -1150,9 +1128,6 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                                 const uint32_t c = sub + (static_cast<uint32_t>(i) << shift);   // interleaved: the item's lanes read consecutive records
                                 const float4 sp = cs[c];
                                 m8 |= sphere_keep(sp.x, sp.y, sp.z, sp.w, r) ? (1u << c) : 0u;
-#ifdef PT_SPHERE_SCHED
-                                if ((i + 1) % PT_SPHERE_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
                             }
                         };
                         if (shift == 0u) test(std::integral_constant<int, 8>());
@@ -1223,12 +1198,8 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                 auto quad = [&](uint32_t k0) {
                     const CullRec rec = load_cull(bp + 12 * k0);
 #pragma unroll
-                    for (int k = 0; k < R; ++k) {
+                    for (int k = 0; k < R; ++k)
                         if (PT_SLOT_ON(k)) m[k] |= (~cull_reject_quad(rec, q[k], k1, k2, a_max, m0q, t_guard) & 3u) << k0;
-#ifdef PT_WALL_SCHED_RAY
-                        __builtin_amdgcn_sched_barrier(0);
-#endif
-                    }
                 };
                 auto single = [&](uint32_t slot) {
                     const CullRec rec = load_cull(bp + 12 * slot);
@@ -1271,12 +1242,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                             }
                         }
                     } else {
-                        for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {
-                            quad(k0);
-#ifdef PT_WALL_SCHED
-                            __builtin_amdgcn_sched_barrier(0);
-#endif
-                        }
+                        for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) quad(k0);
                     }
                 } else
                 for (uint32_t k0 = 0; k0 < cnt32; k0 += 2) {   // records are padded to whole words
@@ -1352,9 +1318,6 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     const uint4 *np = reinterpret_cast<const uint4 *>(a.bvh + node);
                     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     const float ix = lds.rinv.v[0][src], iy = lds.rinv.v[1][src], iz = lds.rinv.v[2][src];
-#ifdef PT_BOX_SCHED_LOADS
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
 #if PT_BOX_F16
                     static_assert(!PT_BOX_SPREAD, "the half-precision test handles a node's eight children in one lane");
                     if (shift == 0u) m8 = box_children_kept_h(q0, q1, q2, q3, r, ix, iy, iz, t_best, a.bvh_err);
@@ -1371,9 +1334,6 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
                     leaf = ((q0.w >> 11) & 1u) != 0u;                       // BvhNode::meta
                     base = leaf ? (q0.w >> 12) * kFan : (q0.w >> 12);      // a leaf's first slot / an inner node's first child
                 }
-#ifdef PT_BOX_SCHED_AFTER
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 kids = __builtin_popcount(m8);
                 keep = cnt;
                 // Children of inner nodes go back on the stack, triangles of leaves into the pair queue.  One prefix sum serves both
