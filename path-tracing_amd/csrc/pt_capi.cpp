@@ -1127,6 +1127,7 @@ int pt_test_set_mutation(const char *family, double value) {
     else if (f == "bvh_mode") m.bvh_mode = static_cast<int>(value);
     else if (f == "bvh_depth_cap") m.bvh_depth_cap = static_cast<int>(value);
     else if (f == "big_threshold") m.big_threshold = static_cast<int>(value);
+    else if (f == "max_clusters") m.max_clusters = static_cast<int>(value);
     else if (f == "items_per_slot") g_items_per_slot = static_cast<int>(value);
     else if (f == "tile_width") g_force_tile_width = static_cast<int>(value);
     else return fail(PT_ERR_INVALID_ARGUMENT, "unknown mutation family " + f);

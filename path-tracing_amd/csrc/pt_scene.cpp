@@ -1066,7 +1066,11 @@ void build_cull_tables(const HostScene &s, float eps_f, CullTables &out) {
             build_bvh(s, geo, cen, ids, eps_line, out, order);
         }
     } else if (!groups.empty()) {
-        if (static_cast<int>(groups.size()) > kMaxClusters) {   // a cloud of loose triangles: one tree over all of them
+        int max_clusters = kMaxClusters;
+#ifdef PT_TEST_HOOKS
+        if (g_cull_mutation.max_clusters >= 0) max_clusters = g_cull_mutation.max_clusters;
+#endif
+        if (static_cast<int>(groups.size()) > max_clusters) {   // a cloud of loose triangles: one tree over all of them
             std::vector<int> all;
             for (const auto &g : groups) all.insert(all.end(), g.begin(), g.end());
             groups.assign(1, all);

@@ -159,6 +159,7 @@ struct CullMutation {
     int no_last_segment_filter = 0;   // integrator: 1 = a path's last segment searches all triangles like every other segment
     double bvh_fill = 0.5;    // box tree: target fill of a node's children (builder tuning; uniform-depth builder)
     int bvh_depth_cap = kMaxBvhDepth;   // SAH trees deeper than this are replaced by the uniform-depth tree (tests raise it to see the refusal)
+    int max_clusters = -1;    // small scenes: more connected groups than this are merged into one sphere tree (-1 = kMaxClusters)
     int big_threshold = -1;   // triangles above which a scene takes the box-tree path: -1 = the library's (kBigSceneTriangles)
     int bvh_mode = -1;        // box tree builder: -1 = the library's default, 0 = uniform depth, 1 = binary SAH collapsed to 8-wide nodes
     int order_mode = 0;   // small-scene clusters: 0 = cheaper of (cells, patches), 1 = as filed, 2 = cells, 3 = patches
