@@ -368,9 +368,9 @@ def cxx_frame_leg(n_bands, W, H, spp, steps, warmup, rehearse, error=-1.0, model
     if rehearse:
         cmd += ["-REHEARSE", "1"]
     try:
-        r = run_group(cmd, 300)
+        r = run_group(cmd, 150)     # (a frame loop of a second or two + RCCL start-up; a hang must not eat the run's budget)
     except subprocess.TimeoutExpired:
-        return {"error": "pt_render timed out"}
+        return {"error": "pt_render timed out after 150 s (killed with its process group)"}
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": f"pt_render rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
@@ -666,7 +666,7 @@ def main():
                     cxx["configs3_strong"] = cxx_frame_leg(world, C3_W, C3_H, C3_SPP, max(1, min(args.steps, 5)), 1, args.rehearse_on_one_gpu)
                 store.set("cxx_frame_done", "1")
             else:
-                store.wait(["cxx_frame_done"], datetime.timedelta(seconds=900))   # two children of at most 300 s each
+                store.wait(["cxx_frame_done"], datetime.timedelta(seconds=450))   # two children of at most 150 s each
         else:
             cxx = {"weak": cxx_frame_leg(1, W, H, args.spp, max(1, min(args.steps, 10)), 1, False)}
 
