@@ -1787,7 +1787,7 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
                 // The primary-ray code (Philox, two double-precision divisions, a normalisation) costs about a third of a segment
                 // however few lanes run it, so it runs only once a.regen_min_dead slots of the wave wait for a path, or when no
                 // ray of the wave is alive (a.regen_min_dead = 64: the wave's passes stay in step, as without regeneration).  The
-                // host sets it per launch (enqueue_render): 1 from -MRR 5 up, 64 below -- measured on Tor.obj without its back
+                // host sets it per launch (enqueue_render): 4 from -MRR 5 up, 64 below -- measured on Tor.obj without its back
                 // wall, 1080p x 64 spp (profiles/r04_regen_sweep.jsonl; Msamples/s at 1 / 16 / 32 / 64): -MRR 8 6 980 / 6 650 / 6 210 /
                 // 5 350, -MRR 5 8 250 / 8 030 / 7 710 / 8 100, -MRR 3 11 260 / 11 360 / 12 740 / 13 390.  Making the rays in advance and
                 // in batches (a ray in store per slot) was built and measured too: +1 % at -MRR 8, -16 % at -MRR 3 still -- a slot

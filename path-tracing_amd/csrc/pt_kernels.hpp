@@ -12,8 +12,10 @@ constexpr uint32_t kPhiloxKey1 = 0x50544831u;   // "PTH1": second Philox key wor
 // Path regeneration (pt_kernels.hip: REGEN; skybox instantiations): new paths are started once this many ray slots of the wave
 // wait for one.  1 = at once; 64 = only when no ray of the wave is alive, i.e. the passes stay in step.  The crossover is
 // between -MRR 3 and -MRR 5 (profiles/r04_regen_sweep.jsonl): short paths leave few lanes idle and the primary-ray code costs a
-// third of a segment whenever it runs.
-constexpr uint32_t regen_min_dead_for(int mrr) { return mrr >= 5 ? 1u : 64u; }
+// third of a segment whenever it runs.  From -MRR 5 up: 4 -- on an open scene 1.3 % behind "at once" (7 517 / 7 617 Msamples/s), and
+// a CLOSED room that happens to have a skybox (two thirds of a lane ends per iteration there) keeps its passes in step instead
+// of running that code in every other iteration (5 753 against 5 287 at 1, 5 790 at 8; r04_ab_logs.txt regen3).
+constexpr uint32_t regen_min_dead_for(int mrr) { return mrr >= 5 ? 4u : 64u; }
 
 struct RenderArgs {
     const ClusterDesc *clusters;   // cull hierarchy (pt_scene.hpp: CullTables), read through the scalar cache

@@ -41,7 +41,8 @@ def main():
     buf = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
     ptrs = (buf.data_ptr(), buf.data_ptr() + 12 * W * H, buf.data_ptr() + 24 * W * H)
     stream = torch.cuda.current_stream(dev)
-    all_scenes = {"closed": ("closed room", os.path.join(ROOT, "models") + "/", "Tor.obj", False), "open_sky": ("open + skybox", tmp, "TorOpen.obj", True),
+    all_scenes = {"closed": ("closed room", os.path.join(ROOT, "models") + "/", "Tor.obj", False),
+                  "closed_sky": ("closed room + skybox (sampled by the rays that slip through)", os.path.join(ROOT, "models") + "/", "Tor.obj", True), "open_sky": ("open + skybox", tmp, "TorOpen.obj", True),
                   "open": ("open, no skybox", tmp, "TorOpen.obj", False), "x9_open_sky": ("x9 open + skybox (box tree)", tmp, "X9Open.obj", True)}
     import hashlib
     for key, regen in [(k, r) for k in a.scenes.split(",") for r in ([int(x) for x in a.regen.split(",")] if a.regen else [None])]:
