@@ -103,6 +103,30 @@ def test_every_segment_of_the_x64_replica_on_the_shipped_instantiation(tmp_path,
     assert st["verify_checked"] > 7 * 1920 * 1080 * 4 and st["verify_mismatches"] == 0
 
 
+@pytest.mark.parametrize("big", [False, True], ids=["small", "box_tree"])
+def test_every_segment_of_an_open_scene_under_a_sky(tmp_path, vlib, big):
+    """The skybox instantiations (path regeneration: every lane in a pass of its own) as a caller without pt_render_stats runs
+    them: Tor.obj -- and the torus x5, a box-tree scene -- without the back wall, under a sky bitmap, adaptive sampling on: every
+    segment's closest hit against the all-triangles loop, and the verified frame = the shipped library's frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_open_scene as MO
+    import make_replicated_scene as M
+    d = str(tmp_path) + "/"
+    src, src_dir = "Tor.obj", None
+    if big:
+        M.generate(os.path.join(ROOT, "models"), d, "x5.obj", 5)
+        src, src_dir = "x5.obj", d
+    MO.generate(os.path.join(ROOT, "models"), d, name="Open.obj", source=src, source_dir=src_dir)
+    v = pt.Scene.load_obj(d, "Open.obj", device=0, library=vlib)
+    v.set_skybox(d + "sky.bmp")
+    s, s2, c, st = v.render_host(960, 540, 24, 8, error=0.01)
+    assert st["verify_checked"] > 960 * 540 * 24 * 0.5 and st["verify_mismatches"] == 0, st
+    g = pt.Scene.load_obj(d, "Open.obj", device=0)
+    g.set_skybox(d + "sky.bmp")
+    q = g.render_host(960, 540, 24, 8, error=0.01, want_stats=False)
+    assert _digest(*q[:3]) == _digest(s, s2, c)
+
+
 @pytest.mark.parametrize("scene", ["tor", "x9"])
 def test_the_check_notices_a_forgotten_emitter(tmp_path, models_dir, vlib, scene):
     """Negative control: the table builder is told to forget one emitter of the large class (test hook emis_drop); the

@@ -34,6 +34,9 @@ def main():
     for n in (64, 195):
         M.generate(os.path.join(ROOT, "models"), tmp, f"TorX{n}.obj", n)
         scenes[f"TorX{n}.obj"] = (tmp, f"TorX{n}.obj")
+    import make_open_scene as MO
+    MO.generate(os.path.join(ROOT, "models"), tmp)             # Tor.obj without its back wall + sky.bmp (row N1: path regeneration)
+    scenes["TorOpen.obj"] = (tmp, "TorOpen.obj")
     import shuffle_obj
     shuffle_obj.shuffle(os.path.join(ROOT, "models", "Tor.obj"), tmp + "TorShuffled.obj")
     scenes["TorShuffled.obj"] = (tmp, "TorShuffled.obj")
@@ -48,6 +51,8 @@ def main():
         ("2-adaptive", "Tor.obj", 1920, 1080, 64, 8, 0.001),
         ("3", "Tor.obj", 1920, 1080, 1024, 8, -1.0),
         ("4-one-gpu", "Tor.obj", 3840, 2160, 256, 8, -1.0),
+        ("open-sky", "TorOpen.obj", 1920, 1080, 256, 8, -1.0),
+        ("open-sky-mrr3", "TorOpen.obj", 1920, 1080, 256, 3, -1.0),
         ("5-x64", "TorX64.obj", 1920, 1080, 256, 8, -1.0),
         ("5-x195", "TorX195.obj", 1920, 1080, 256, 8, -1.0),
     ]
@@ -58,6 +63,8 @@ def main():
             continue
         spp = max(1, int(round(spp * a.spp_scale)))
         sc = pt.Scene.load_obj(*scenes[scene_name], device=0)
+        if scene_name == "TorOpen.obj":
+            sc.set_skybox(tmp + "sky.bmp")
         n = W * H
         buf = torch.zeros(7 * n, dtype=torch.float32, device=dev)
         p = pt.RenderParams(W, H, 0, H, 0, spp, mrr, 1e-4, err, 42)
@@ -82,6 +89,7 @@ def main():
                "node_rounds_per_wave_segment": round(st["wave_node_rounds"] / max(1, st["wave_segments"]), 2),
                "exact_rounds_per_wave_segment": round(st["wave_exact_iterations"] / max(1, st["wave_segments"]), 2),
                "partial_commit_rounds": st["partial_commit_rounds"],
+               "live_rays_per_wave_segment": round(st["segments"] / max(1, st["wave_segments"]), 2),
                "contributing_fraction": round(st["contributing"] / max(1, st["samples_traced"]), 5)}
         print(json.dumps(out), flush=True)
         sc.close()
