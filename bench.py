@@ -90,9 +90,10 @@ def host_cores():
 
 
 def instantiation(kernel_name):
-    """integrate_kernel<SKY, BIG, STATS, ENV, NARROW, ADAPT> -> (sky, big, stats, env, narrow, adapt) as booleans, or None."""
+    """integrate_kernel<SKY, BIG, STATS, ENV, NARROW, ADAPT> -> (sky, big, stats, env, narrow, adapt) as booleans (ADAPT is an
+    int: 0 = off), or None."""
     m = re.search(r"integrate_kernel<(\w+),(\w+),(\w+),(\w+)(?:,(\w+))?(?:,(\w+))?>", kernel_name.replace(" ", ""))
-    return tuple(x == "true" for x in m.groups()) if m else None      # (missing trailing arguments read as False)
+    return tuple(x not in (None, "false", "0") for x in m.groups()) if m else None      # (missing trailing arguments read as False)
 
 
 def kernel_source_sha():
@@ -303,7 +304,7 @@ def cpu_baseline(models, target_seconds, pt, scene):
     d = g_rgb.astype(np.float64) - c_rgb.astype(np.float64)
     g_bgr, c_bgr = pt.quantize(g_rgb, gc), pt.quantize(c_rgb, cpu_acc[2])
     accuracy = {"vs": "cpu_baseline sample (same rows, passes, seed; counter RNG on both sides)",
-                "gpu_instantiation": "integrate_kernel<false,false,false,false,false,false> (statistics-free, two pixels per lane: the one the timed launches run)",
+                "gpu_instantiation": "integrate_kernel<false,false,false,false,false,0> (statistics-free, two pixels per lane: the one the timed launches run)",
                 "rmse_rgb_float_image": [float(np.sqrt(np.mean(d[..., k] ** 2))) for k in range(3)],
                 "max_abs_diff_float_image": float(np.abs(d).max()),
                 "bmp_bytes_differing": int(np.count_nonzero(g_bgr != c_bgr)),
@@ -592,7 +593,7 @@ def main():
             if inst == 64:
                 v = valu_view(pmc_big, r["kernel_ms"], float(st["segments"]))
                 rf = {"bound": "valu_issue", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s", **v,
-                      "kernel": "pt::integrate_kernel<false,true,false,false,false,false>", "kernel_ms": r["kernel_ms"],
+                      "kernel": "pt::integrate_kernel<false,true,false,false,false,0>", "kernel_ms": r["kernel_ms"],
                       "issue": issue_view(pmc_big, r["kernel_ms"], wseg), "counters_source": pmc_big_source,
                       "l1_hit_rate": (1 - pmc_big["TCP_TCC_READ_REQ_sum"] / pmc_big["TCP_TOTAL_CACHE_ACCESSES_sum"])
                       if pmc_big and pmc_big.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
@@ -616,7 +617,7 @@ def main():
                      "counters_source": pmc_c2_source,
                      "fetch_kib": pmc_c2.get("FETCH_SIZE") if pmc_c2 else None, "write_kib": pmc_c2.get("WRITE_SIZE") if pmc_c2 else None}
         if args.save_pmc and pmc_c2:
-            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false,false,false>", "width": BASE_W, "height": BASE_H, "spp": C2_SPP, "mrr": MRR,
+            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false,false,0>", "width": BASE_W, "height": BASE_H, "spp": C2_SPP, "mrr": MRR,
                        "kernel_source_sha": kernel_source_sha(), "kernel_ms": c2["kernel_ms"], "counters_per_launch": pmc_c2,
                        "hbm": c2["hbm"], "collected_by": "bench.py --save-pmc (configs2_1024spp): " + pmc_c2_source,
                        "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes over pt_render on the 1024-spp frame"},
@@ -638,7 +639,7 @@ def main():
                                       "source": "profiles/r04_open_scene_probe_before.jsonl (the same scene and kernel before regeneration, another box)"}
         v = valu_view(pmc_sky, sk["kernel_ms"], float(sk_st["segments"]))
         sk["roofline"] = {"bound": "valu_issue", "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s", **v, "kernel_ms": sk["kernel_ms"],
-                          "kernel": "pt::integrate_kernel<true,false,false,false,false,false>", "counters_source": pmc_sky_source,
+                          "kernel": "pt::integrate_kernel<true,false,false,false,false,0>", "counters_source": pmc_sky_source,
                           "issue": issue_view(pmc_sky, sk["kernel_ms"], float(sk_st["wave_segments"]) or None)}
         if args.cpu_seconds > 0:      # parity of THIS leg: a band of the same frame against the oracle, bit for bit
             import oracle_lib as O
@@ -690,7 +691,7 @@ def main():
             # strided accumulator loads, calibrated 0.76-1.0 : 1 on their known byte count
             traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         if args.save_pmc and pmc and pmc_source.startswith("rocprofv3"):
-            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false,false,false>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
+            json.dump({"kernel": "pt::integrate_kernel<false,false,false,false,false,0>", "width": W, "height": H, "spp": args.spp, "mrr": MRR,
                        "kernel_source_sha": kernel_source_sha(), "kernel_ms": kms, "counters_per_launch": pmc,
                        "collected_by": "bench.py --save-pmc: " + pmc_source,
                        "note": "FETCH_SIZE / WRITE_SIZE in KiB from separate --pmc passes; SQ_INSTS_VALU counts wave-instructions"},
@@ -715,7 +716,7 @@ def main():
             "roofline": {"bound": "valu_issue", "achieved": v["achieved"], "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": v["frac"],
                          "traffic": traffic,
-                         "kernel": "pt::integrate_kernel<false,false,false,false,false,false>", "kernel_ms": kms,
+                         "kernel": "pt::integrate_kernel<false,false,false,false,false,0>", "kernel_ms": kms,
                          "what": "achieved = executed VALU lane-operations (SQ_INSTS_VALU x 64) / live HIP-event kernel time; "
                                  "peak = 1024 SIMDs x 32 lanes x 2.4 GHz (no FMA: parity forbids contraction); frac counts issued "
                                  "instructions whatever their lane mask, frac_active_lanes = frac x active-lane fraction, useful_fraction = "

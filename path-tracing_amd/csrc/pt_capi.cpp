@@ -15,7 +15,7 @@
 
 #ifdef PT_TEST_HOOKS
 static int g_items_per_slot = 0;
-static int g_force_tile_width = 0;   // 1 = always 8 x 8 tiles, 2 = always the widest the instantiation has, 0 = by tile count
+static int g_force_tile_width = 0;   // 1 = always 8 x 8 tiles, 2 = always 16 x 8 where the instantiation has them, 3 = the same and 32 x 8 for adaptive launches, 0 = by tile count
 static int g_regen_min_dead = 0;     // test build: overrides RenderArgs::regen_min_dead (0 = the library's)
 #endif
 
@@ -296,14 +296,30 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
     int32_t chunk_passes = 0;
     if (n_tiles >= slots / 2u)
         while (n_chunks < 6u && (p->pass_count >> (2u * n_chunks)) >= 8) ++n_chunks;
+    // Between about one and two tiles per wave slot the first of those chunks is too coarse -- all tiles' 3/4 of the passes: the
+    // chip runs one full round of them and a second one half empty.  There the pass range is cut into EQUAL chunks, 8 to 32
+    // work items per wave slot: Tor.obj 1366 x 768 x 256 spp 47.5 -> 40.2 ms, 960 x 540 25.7 -> 21.9 ms, and the 32 x 8 tiles of
+    // adaptive 1080p launches (1.58 per slot) 65.2 -> 55.8 ms; from 2.3 tiles per slot up the 3/4 scheme wins again; the open
+    // scene under a sky at 960 x 540 22.2 -> 20.1 ms (profiles/r04_ab_logs.txt, chunks1).
+    int items_per_slot = 0;
+    {
+        const unsigned long long t100 = 100ull * n_tiles;
+        if (a.sky != nullptr) {   // (regenerating kernels: a chunk's end is a tail of idle lanes, so fewer, longer chunks and a narrower range)
+            if (t100 >= 75ull * slots && t100 < 190ull * slots) items_per_slot = 8;
+        } else if (t100 >= 75ull * slots && t100 < 230ull * slots) {
+            items_per_slot = t100 < 120ull * slots ? 8 : t100 < 190ull * slots ? 16 : 32;
+        }
+    }
 #ifdef PT_TEST_HOOKS
-    if (g_items_per_slot > 0) {   // scheduler tuning, test build only: equal chunks, about items_per_slot work items per wave slot
-        n_chunks = (static_cast<uint32_t>(g_items_per_slot) * slots + n_tiles - 1u) / n_tiles;
+    if (g_items_per_slot != 0) items_per_slot = std::max(0, g_items_per_slot);   // scheduler tuning, test build only (< 0: never equal chunks)
+#endif
+    if (items_per_slot > 0) {   // equal chunks, about items_per_slot work items per wave slot
+        n_chunks = (static_cast<uint32_t>(items_per_slot) * slots + n_tiles - 1u) / n_tiles;
         n_chunks = std::max(1u, std::min(n_chunks, static_cast<uint32_t>(std::max(1, p->pass_count / 4))));
         chunk_passes = std::max(1, (p->pass_count + static_cast<int32_t>(n_chunks) - 1) / static_cast<int32_t>(n_chunks));
         n_chunks = static_cast<uint32_t>(std::max(1, (p->pass_count + chunk_passes - 1) / chunk_passes));
+        if (n_chunks == 1u) chunk_passes = 0;
     }
-#endif
     if (static_cast<unsigned long long>(n_tiles) * n_chunks > 0x7fffffffull) return fail(PT_ERR_INVALID_ARGUMENT, "too many work items");
     if (ctx.has_prev && ctx.prev_stream != stream) PT_HIP_TRY(hipStreamWaitEvent(stream, ctx.ev_done, 0));
     if (ctx.sched_words < 1 + static_cast<size_t>(n_tiles)) {

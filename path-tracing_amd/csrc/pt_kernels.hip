@@ -329,6 +329,18 @@ __device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v) {
     return static_cast<uint32_t>(x);
 }
 __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63)); }
+// Minimum over the 64 lanes, wave-uniform: the same six DPP steps with min instead of + (a lane without a source keeps ~0).
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+    int x = static_cast<int>(v);
+    auto step = [&](int moved) { x = static_cast<int>(min(static_cast<uint32_t>(x), static_cast<uint32_t>(moved))); };
+    step(__builtin_amdgcn_update_dpp(-1, x, 0x111, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp(-1, x, 0x112, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp(-1, x, 0x114, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp(-1, x, 0x118, 0xF, 0xF, false));
+    step(__builtin_amdgcn_update_dpp(-1, x, 0x142, 0xA, 0xF, false));
+    step(__builtin_amdgcn_update_dpp(-1, x, 0x143, 0xC, 0xF, false));
+    return wave_last(static_cast<uint32_t>(x));
+}
 // One LDS store per set bit of `bits`: entry = ebase + (bit index << shift), at queue[pos], queue[pos + 1], ...
 __device__ __forceinline__ void emit_bits(uint32_t *queue, uint32_t pos, uint32_t bits, uint32_t ebase, uint32_t shift = 0) {
     while (bits != 0) {
@@ -365,7 +377,7 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {   // 
 // of the instructions went.  Big scenes keep R = 1 (their rounds are full anyway, their registers are not).
 template <int N> struct AccPlanes { float v[7][N]; };
 template <> struct AccPlanes<0> {};
-template <int N> struct FlagWords { uint32_t v[N]; };
+template <int N> struct FlagWords { uint16_t v[N]; };
 template <> struct FlagWords<0> {};
 #ifndef PT_MATS_IN_LDS
 #define PT_MATS_IN_LDS 16   // two-pixel kernels: a scene's materials, if it has at most this many, are read from a copy in LDS
@@ -374,7 +386,7 @@ template <int N> struct InvPlanes { float v[3][N]; };
 template <> struct InvPlanes<0> {};
 template <int N> struct MatCache { float4 v[3 * N]; };
 template <> struct MatCache<0> {};
-template <class Q, int R, bool FLAGS = false>
+template <class Q, int R, int FLAGS = 0>
 struct WaveLds {
     static constexpr int kRays = R, kSlots = 64 * R;
     static constexpr int kNodeStack = Q::kNodeStack, kPairQueue = Q::kPairQueue;
@@ -403,9 +415,12 @@ struct WaveLds {
     // accumulators live"): the LDS is worth a wave per SIMD to them.
     static constexpr bool kAccInLds = R == 1 && !kPrefilter;
     AccPlanes<kAccInLds ? kSlots : 0> acc;
-    // adaptive-sampling instantiation of the two-pixel kernel: the cached "variance is low" answer of the tile's pixels, by pixel
-    // (lane + 64 k): another lane may be the one that traces a lane's second pixel, see "Compaction" in integrate_kernel
-    FlagWords<FLAGS ? kSlots : 0> low;
+    // adaptive-sampling instantiations of the two-pixel kernel: one 16-bit word per pixel of the tile (FLAGS per lane: pixel lane +
+    // 64 j) -- the pixel's next pass << 1 | the cached "variance is low" answer (launches whose passes end beyond kMaxBatchPass
+    // run the plain kernel); any lane may be the one that traces it, see "Batches" in integrate_kernel.  (16 bits: with 32-bit
+    // words the 32 x 8 instantiation's 7 888 B of LDS round up to seven 1 280-byte granules and cost it its fifth wave per SIMD:
+    // +13 % frame time, profiles/r04_ab_logs.txt adapt2)
+    FlagWords<64 * FLAGS> low;
     // Shading reads the hit's record and then, through its material index, the material: two dependent loads.  The two-pixel
     // kernels take the second from a copy in LDS when the scene has at most kMatCache materials (Tor.obj: 5): +0.8 % (256 spp:
     // 73.2 -> 72.6 ms; with adaptive sampling +1.3 %); the box-tree kernel gains nothing from it (ab64) and does without.
@@ -1441,6 +1456,10 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 #ifndef PT_RAYS_PER_LANE
 #define PT_RAYS_PER_LANE 2   // pixels (rays) per lane of the small-scene, statistics-free, skybox-free kernel; 1 = one 8 x 8 tile per wave
 #endif
+constexpr int kMaxBatchPass = 32766;   // adaptive instantiations: a pixel's next pass (at most one past the launch's last) << 1 | a flag in 16 bits
+#ifndef PT_ADAPT_TWO_AT
+#define PT_ADAPT_TWO_AT 120   // adaptive kernel: pixels of a tile (of 128) with a pass to run from which a batch takes them all, two per lane
+#endif
 #ifndef PT_BIG_RAYS_PER_LANE
 #define PT_BIG_RAYS_PER_LANE 1   // the same for the statistics-free, skybox-free big-scene kernel
 #endif
@@ -1450,12 +1469,19 @@ constexpr int rays_per_lane() { return (!SKY && !STATS) ? (BIG ? PT_BIG_RAYS_PER
 
 // NARROW = the statistics-free small-scene kernel with ONE pixel per lane (8 x 8 tiles): for launches with too few pixels to
 // fill the chip with 16 x 8 tiles (small previews, thin row bands) -- half as many waves would leave wave slots empty.
-// ADAPT = the two-pixel kernel for launches with adaptive sampling on (error >= 0): see "Compaction" in the pass loop.
-template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW = false, bool ADAPT = false>
-__global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES /* (that one spills at 5) */ : PT_SKY_WAVES) : BIG ? PT_BIG_WAVES : (STATS || (!NARROW && rays_per_lane<SKY, BIG, STATS>() > 1)) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD) void integrate_kernel(const RenderArgs a) {
+// waves per SIMD an instantiation is compiled for
+template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW>
+constexpr int integrator_waves() {
+    return SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES /* (that one spills at 5) */ : PT_SKY_WAVES)
+               : BIG ? PT_BIG_WAVES : (STATS || (!NARROW && rays_per_lane<SKY, BIG, STATS>() > 1)) ? PT_WAVES_PER_SIMD - 1 : PT_WAVES_PER_SIMD;
+}
+// ADAPT = the two-pixel kernel for launches with adaptive sampling on (error >= 0), with tiles of 64 ADAPT pixels (2: 16 x 8,
+// 4: 32 x 8): see "Batches" in the pass loop.
+template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW = false, int ADAPT = 0>
+__global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NARROW>())) void integrate_kernel(const RenderArgs a) {
     static_assert(!NARROW || (!SKY && !STATS), "only the statistics-free, skybox-free kernels have a narrow variant");
     constexpr int R = NARROW ? 1 : rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
-    static_assert(!ADAPT || (R == 2 && !BIG), "compaction moves a lane's second pixel into another lane's free first slot");
+    static_assert(ADAPT == 0 || ((ADAPT == 2 || ADAPT == 4) && R == 2 && !BIG && !STATS && !SKY), "batches of the tile's pixels, two ray slots per lane; a pixel's number takes 8 bits");
     // REGEN = path regeneration: a lane whose path has ended starts its pixel's NEXT pass at once instead of idling until the
     // longest path of the wave is done.  The skybox instantiations run this way: a scene with a skybox is an open scene, most
     // paths end on their first or second segment (scene.cpp:125-155: a miss ends the path) -- Tor.obj without its back wall has
@@ -1466,7 +1492,8 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
     // nothing and would cost the last-segment filter, which needs the wave's rays to reach their last segment together.
     constexpr bool REGEN = SKY;
     static_assert(!REGEN || !ADAPT, "the compacting instantiation keeps the pass loop");
-    constexpr int kTW = kTileW * R;
+    constexpr int kOwn = ADAPT ? ADAPT : R;   // pixels of the tile per lane: pixel j of the tile = column (j % 8) + 8 (j / 64), row (j % 64) / 8
+    constexpr int kTW = kTileW * kOwn;
     __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R, ADAPT> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
@@ -1507,7 +1534,11 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
         __builtin_amdgcn_wave_barrier();
     }
     // a.blocks_x counts tiles of THIS instantiation's width (the host asks integrator_tile_width)
-    const int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTW, tile_y0 = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;   // wave-uniform
+    int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTW, tile_y0 = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;   // wave-uniform
+    if constexpr (ADAPT != 0) {   // (the division runs on the vector unit: say that its results are scalars, or the 16 x 8 kernel spills one of them)
+        tile_x0 = __builtin_amdgcn_readfirstlane(tile_x0);
+        tile_y0 = __builtin_amdgcn_readfirstlane(tile_y0);
+    }
     // pixel k of the lane: column (lane % 8) + 8 k of the tile, row lane / 8; its slot in the wave's LDS arrays is lane + 64 k
     int x[R];
     const int y = tile_y0 + (lane / kTileW);
@@ -1559,7 +1590,9 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         lowvar[k] = false;
-        if constexpr (!kAccInLds) {
+        if constexpr (ADAPT) {
+            // (the answers of this instantiation live in LDS, by pixel: below)
+        } else if constexpr (!kAccInLds) {
             if (in_image[k]) {
                 const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + x[k];
                 lowvar[k] = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
@@ -1570,12 +1603,24 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
                                                       lds.acc.v[5][id], __float_as_int(lds.acc.v[6][id]));
         }
     }
-    // ADAPT: the pixel the lane's FIRST ray slot works on in the current pass -- owner lane | column block << 6: its own first
-    // pixel (= lane), or, in a compacted pass, another lane's second pixel (see "Compaction" in the pass loop).
-    uint32_t job0 = static_cast<uint32_t>(lane);
+    // ADAPT: the pixels of the tile (number j = owner lane | column block << 6) the lane's two ray slots work on in the current
+    // batch: slot 0's in bits 0-7, slot 1's in bits 8-15 (see "Batches" in the pass loop).  Everything about a traced pixel --
+    // camera ray, RNG counter, accumulator address, pass -- is derived from its number where it is needed.
+    uint32_t jobs = 0;
+    auto job_of = [&](int k) { return (opaque(jobs) >> (8 * k)) & 0xFFu; };
+    auto tile_x_of = [&](uint32_t j) { return tile_x0 + static_cast<int>((j & 63u) % kTileW) + kTileW * static_cast<int>(j >> 6); };
+    auto tile_y_of = [&](uint32_t j) { return tile_y0 + static_cast<int>((j & 63u) / kTileW); };
     if constexpr (ADAPT) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) lds.low.v[lane + 64 * k] = lowvar[k] ? 1u : 0u;
+        for (int kb = 0; kb < kOwn; ++kb) {   // the lane's own pixels: next pass | answer
+            const uint32_t j = static_cast<uint32_t>(lane) + 64u * kb;
+            bool low = false;
+            if (tile_x_of(j) < a.width && y < a.row_end) {
+                const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + tile_x_of(j);
+                low = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
+            }
+            lds.low.v[j] = static_cast<uint16_t>((static_cast<uint32_t>(pass_first) << 1) | (low ? 1u : 0u));
+        }
         wave_sync();
     }
     // adds one contribution (material.h:74-77) to pixel k of the lane and refreshes its cached adaptive-sampling answer
@@ -1584,14 +1629,13 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
         int nn;
         if constexpr (!kAccInLds) {
             // (the pixel's index is rebuilt from the lane number and the tile's wave-uniform corner, like the camera ray's x, y)
+            // (opaque: or the addresses are formed at the head of the pass and held -- spilled -- until here)
             uint32_t le = opaque(static_cast<uint32_t>(lane));
             int kb = k;
             if constexpr (ADAPT) {
-                if (k == 0) {   // (opaque: or the addresses are formed at the head of the pass and held -- spilled -- until here)
-                    const uint32_t j = opaque(job0);
-                    le = j & 63u;
-                    kb = static_cast<int>(j >> 6);
-                }
+                const uint32_t j = job_of(k);
+                le = j & 63u;
+                kb = static_cast<int>(j >> 6);
             }
             const size_t p = static_cast<size_t>(tile_y0 + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * kb);
             n0 = a.sum[3 * p] + cr; n1 = a.sum[3 * p + 1] + cg; n2 = a.sum[3 * p + 2] + cb;
@@ -1611,8 +1655,10 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
         }
         const bool now_low = low_variance(n0, n1, n2, p0, p1, p2, nn);
         if constexpr (ADAPT) {
-            // (the answers live in LDS, by pixel, whoever traces it; the owners read them at the head of every pass)
-            lds.low.v[k == 0 ? opaque(job0) : static_cast<uint32_t>(lane) + 64u] = now_low ? 1u : 0u;
+            // (the answers live in LDS, by pixel, whoever traces it -- bit 0 of the pixel's word, its next pass above --; the owners
+            // read them at the head of every batch)
+            const uint32_t pj = job_of(k);
+            lds.low.v[pj] = static_cast<uint16_t>((lds.low.v[pj] & ~1u) | (now_low ? 1u : 0u));
         } else {
             lowvar[k] = now_low;
         }
@@ -1630,6 +1676,12 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
 #ifdef PT_VERIFY_SHIPPED
     uint32_t v_checked = 0, v_bad = 0;   // wave-uniform
     uint32_t v_compacted = 0;            // passes a wave ran compacted (ADAPT): reported where this build has no other use for a field
+#endif
+#ifdef PT_ADAPT_COUNT
+    // diagnostic build (make variant DEFS=-DPT_ADAPT_COUNT): what the batches of the adaptive instantiations held, reported in the
+    // statistics block's fields: samples_traced = rays, wave_node_rounds / wave_exact_iterations = one- / two-slot batches,
+    // segments / wave_segments = segment-loop iterations inside one- / two-slot batches
+    uint32_t c_rays = 0, c_one = 0, c_two = 0, c_seg1 = 0, c_seg2 = 0;
 #endif
     auto any_of = [&](const bool (&b)[R]) {   // wave-uniform: any ray of the wave
         bool v = b[0];
@@ -1650,63 +1702,109 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
         cur_pass[k] = next_pass[k] = pass_first;
         q[k].ox = q[k].oy = q[k].oz = 0.0f; q[k].dx = q[k].dy = 0.0f; q[k].dz = 1.0f;
     }
-    for (int pass = pass_first; REGEN ? pass == pass_first : pass < pass_last; ++pass) {   // (REGEN: one trip, the loop inside runs all passes)
+    for (int pass = pass_first; ADAPT ? true : REGEN ? pass == pass_first : pass < pass_last; ++pass) {   // (REGEN: one trip, the loop inside runs all passes; ADAPT: one trip per batch)
         // Adaptive skip, main.cpp:118-125.
         bool skip[R], traced[R];
-        if constexpr (ADAPT) {
-            wave_sync();   // (the flags written while shading the last pass, possibly by other lanes)
-#pragma unroll
-            for (int k = 0; k < R; ++k) lowvar[k] = lds.low.v[lane + 64 * k] != 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            skip[k] = !in_image[k] || (pass > 10 && (pass % 4) && lowvar[k]);
-            if constexpr (REGEN) skip[k] = true;   // (paths are started inside the segment loop)
-            traced[k] = !skip[k];
-        }
-        if constexpr (!REGEN) {
-            if (!any_of(traced)) continue;
-        }
-        // Compaction (ADAPT).  With adaptive sampling on, most pixels of a tile sit out most passes of the second half of a
-        // frame (Tor.obj, -ERR 0.001, 256 spp: 46 of a tile's 128 pixels are still traced at the end), scattered over the tile:
-        // a wave with two pixels per lane would run nearly every pass at full cost for a third of the rays.  So a pass in which
-        // at most 64 of the tile's pixels are traced moves every traced SECOND pixel into the free first slot of some other
-        // lane (ranks by ballot, the lane numbers through LDS) and runs with the second slots switched off (`two`): about the
-        // cost of a one-pixel-per-lane pass.  A pixel's samples do not depend on the lane that traces them (the counter RNG is
-        // keyed by the pixel, the search returns the minimum over the same candidates), so the frame does not change.
         bool two = true;   // wave-uniform: some lane's second ray slot is in use this pass
-        // the RNG's pixel index of ray slot k (ADAPT: slot 0's is rebuilt from job0 where it is used, not kept in a register)
+        if constexpr (!ADAPT) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                skip[k] = !in_image[k] || (pass > 10 && (pass % 4) && lowvar[k]);
+                if constexpr (REGEN) skip[k] = true;   // (paths are started inside the segment loop)
+                traced[k] = !skip[k];
+            }
+            if constexpr (!REGEN) {
+                if (!any_of(traced)) continue;
+            }
+        }
+        // Batches (ADAPT).  With adaptive sampling on, most pixels of a tile sit out three passes of four in the second half of a
+        // frame (Tor.obj, -ERR 0.001, 256 spp: a third of the pixels are still traced at the end), scattered over the tile: a wave
+        // that runs the tile pass by pass, two pixels per lane, pays nearly every pass in full for a third of the rays.  So this
+        // instantiation does not run passes, it runs BATCHES.  Every pixel of the tile (64 ADAPT of them: twice as many as ray
+        // slots with 32 x 8 tiles) has its own next pass (lds.low: pass << 1 | "variance is low"), stepped over the passes it
+        // sits out; a batch takes pixels that still have a pass to run in this work item, each at ITS next pass: up to 128, two
+        // per lane, if at least PT_ADAPT_TWO_AT wait; otherwise up to 64, one per lane, with the second ray slots switched off
+        // (`two`: 0.65 of the cost of a two-slot batch, profiles/r04_ab_logs.txt adapt1).  When more wait than a batch takes,
+        // those that are furthest behind go first (all at the smallest next pass, then the others in pixel order), so that
+        // the tile's pixels finish together.  The chosen pixels' numbers are compacted into a list (ranks by ballot and prefix
+        // over the column blocks); ray slot k of lane l traces entry l + 64 k.
+        // A pixel's passes still run in order, one per batch at most: its contributions are added in pass order and its
+        // adaptive-sampling answer is the one main.cpp:118-125 computes before that pass (it changes only when the pixel's own
+        // path contributes).  A sample does not depend on the lane or the batch that traces it (the counter RNG is keyed by pixel
+        // and pass, the search returns the minimum over the same candidates), so the frame does not change.
+        // the RNG's pixel index of ray slot k
         auto rng_pixel = [&](int k) {
             if constexpr (ADAPT) {
-                if (k == 0) {
-                    const uint32_t jl = opaque(job0) & 63u;
-                    return static_cast<uint32_t>(static_cast<size_t>(tile_y0 + static_cast<int>(jl / kTileW)) * a.width +
-                                                 (tile_x0 + static_cast<int>(jl % kTileW) + kTileW * static_cast<int>(opaque(job0) >> 6)));
-                }
+                const uint32_t j = job_of(k);
+                return static_cast<uint32_t>(static_cast<size_t>(tile_y_of(j)) * a.width + tile_x_of(j));
             }
             return opaque(gpix[k]);
         };
         if constexpr (ADAPT) {
-            job0 = static_cast<uint32_t>(lane);
-            const unsigned long long b0 = __ballot(traced[0]), b1 = __ballot(traced[1]);
-            const uint32_t n0 = __builtin_popcountll(b0), n1 = __builtin_popcountll(b1);
-            if (n1 == 0) {
-                two = false;
-            } else if (n0 + n1 <= 64u) {
-                two = false;
-                if (traced[1]) lds.pairs[lanes_below(b1)] = static_cast<uint32_t>(lane);   // (the queues are empty between two searches)
-                wave_sync();
-                const uint32_t free_rank = lanes_below(~b0);
-                if (!traced[0] && free_rank < n1) {
-                    job0 = lds.pairs[free_rank] | 64u;
-                    skip[0] = false;
-                }
-                skip[1] = true;
-                wave_sync();
-#ifdef PT_VERIFY_SHIPPED
-                ++v_compacted;
-#endif
+            wave_sync();   // (the answers written while shading the last batch, by whichever lane traced the pixel)
+            uint32_t word[kOwn], np[kOwn];
+            bool pend[kOwn], sel[kOwn];
+            unsigned long long pb[kOwn];
+            const uint32_t le = opaque(static_cast<uint32_t>(lane));   // (or the words' addresses are kept -- spilled -- across the batch)
+            uint32_t n_pend = 0, behind = ~0u;
+#pragma unroll
+            for (int kb = 0; kb < kOwn; ++kb) {
+                const uint32_t j = le + 64u * kb;
+                word[kb] = lds.low.v[j];
+                np[kb] = word[kb] >> 1;
+                if (np[kb] > 10u && (np[kb] & 3u) && (word[kb] & 1u)) np[kb] = (np[kb] + 3u) & ~3u;   // sits out until the next multiple of 4
+                pend[kb] = tile_x_of(j) < a.width && tile_y_of(j) < a.row_end && static_cast<int>(np[kb]) < pass_last;
+                sel[kb] = pend[kb];
+                pb[kb] = __ballot(pend[kb]);
+                n_pend += __builtin_popcountll(pb[kb]);
+                behind = min(behind, pend[kb] ? np[kb] : ~0u);
             }
+            if (n_pend == 0) break;
+            const uint32_t quota = n_pend >= static_cast<uint32_t>(PT_ADAPT_TWO_AT) ? 128u : 64u;
+            if (n_pend > quota) {
+                const uint32_t m = wave_min(behind);
+                uint32_t at_a = 0, at_b = 0, rank_a[kOwn], rank_b[kOwn];
+                bool is_a[kOwn];
+#pragma unroll
+                for (int kb = 0; kb < kOwn; ++kb) {
+                    is_a[kb] = pend[kb] && np[kb] == m;
+                    const unsigned long long ab = __ballot(is_a[kb]), bb = pb[kb] & ~ab;
+                    rank_a[kb] = at_a + lanes_below(ab);
+                    rank_b[kb] = at_b + lanes_below(bb);
+                    at_a += __builtin_popcountll(ab);
+                    at_b += __builtin_popcountll(bb);
+                }
+                const uint32_t quota_b = at_a >= quota ? 0u : quota - at_a;
+#pragma unroll
+                for (int kb = 0; kb < kOwn; ++kb) sel[kb] = is_a[kb] ? rank_a[kb] < quota : (pend[kb] && rank_b[kb] < quota_b);
+            }
+            uint32_t n_sel = 0;
+#pragma unroll
+            for (int kb = 0; kb < kOwn; ++kb) {
+                const unsigned long long sb = __ballot(sel[kb]);
+                if (sel[kb]) lds.pairs[n_sel + lanes_below(sb)] = le + 64u * kb;   // (the queues are empty between two searches)
+                n_sel += __builtin_popcountll(sb);
+            }
+            wave_sync();
+            two = n_sel > 64u;
+#ifdef PT_ADAPT_COUNT
+            c_rays += n_sel;
+            if (two) ++c_two; else ++c_one;
+#endif
+            jobs = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                skip[k] = le + 64u * k >= n_sel;
+                traced[k] = !skip[k];
+                if (traced[k]) jobs |= lds.pairs[le + 64u * k] << (8 * k);
+            }
+#ifdef PT_VERIFY_SHIPPED
+            if (__any((traced[0] && (jobs & 0xFFu) != le) || (traced[1] && (jobs >> 8) != le + 64u))) ++v_compacted;
+#endif
+            wave_sync();   // (the list was in the pair queue: read before the search fills that)
+#pragma unroll
+            for (int kb = 0; kb < kOwn; ++kb)   // the owners: the chosen pixels' next pass
+                lds.low.v[le + 64u * kb] = static_cast<uint16_t>(((np[kb] + (sel[kb] ? 1u : 0u)) << 1) | (word[kb] & 1u));
         }
         const bool k1_on = two;   // (PT_SLOT_ON)
 
@@ -1728,10 +1826,8 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
                     yi = tile_y0 + static_cast<int>(opaque(static_cast<uint32_t>(lane)) / kTileW);
                 }
                 if constexpr (ADAPT) {
-                    if (k == 0) {
-                        xi = tile_x0 + static_cast<int>((job0 & 63u) % kTileW) + kTileW * static_cast<int>(job0 >> 6);
-                        yi = tile_y0 + static_cast<int>((job0 & 63u) / kTileW);
-                    }
+                    xi = tile_x_of(job_of(k));
+                    yi = tile_y_of(job_of(k));
                 }
                 int wi = a.width, hi = a.height;
                 asm volatile("" : "+v"(xi), "+v"(yi), "+s"(wi), "+s"(hi));
@@ -1754,25 +1850,29 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
             primary_dir(k, pass_k, ddx, ddy, ddz);
             start_path(k, ddx, ddy, ddz);
         };
+        // the pass of ray slot k's path: the wave's (a scalar) -- or, with regeneration or batches, the slot's own
+        auto pass_of = [&](int k) {
+            if constexpr (ADAPT) {   // (a traced pixel's word holds the pass AFTER this one: read where needed, a register would spill)
+                return static_cast<int>(lds.low.v[job_of(k)] >> 1) - 1;
+            } else if constexpr (REGEN) {
+                return cur_pass[k];
+            } else {
+                return pass;
+            }
+        };
         if constexpr (!REGEN) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 tr[k] = tg[k] = tb[k] = 1.0f;
                 depth[k] = mrr;
                 if (PT_SLOT_ON(k) && !skip[k]) {
-                    primary_ray(k, pass);
+                    primary_ray(k, pass_of(k));
                 } else {
                     q[k].ox = q[k].oy = q[k].oz = 0.0f; q[k].dx = q[k].dy = 0.0f; q[k].dz = 1.0f;
                 }
                 if constexpr (STATS) n_traced += __builtin_popcountll(__ballot(!skip[k]));
             }
         }
-        // the pass of ray slot k's path: the wave's (a scalar) -- or, with regeneration, the lane's own
-        auto pass_of = [&](int k) {
-            if constexpr (REGEN) return cur_pass[k];
-            else return pass;
-        };
-
         for (;;) {
             bool valid[R];
 #pragma unroll
@@ -1820,6 +1920,9 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
                 }
             }
             if (!any_of(valid)) break;
+#ifdef PT_ADAPT_COUNT
+            if (two) ++c_seg2; else ++c_seg1;
+#endif
             if constexpr (STATS) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) n_segments += __builtin_popcountll(__ballot(valid[k]));
@@ -1891,7 +1994,7 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
             }
             for (;;) {
                 if (BIG && !any_of(searched)) break;
-                closest_hit<ENV, kLastSegmentFilter, ADAPT>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase, two);
+                closest_hit<ENV, kLastSegmentFilter, (ADAPT != 0)>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase, two);
                 if (!emis_phase) break;
                 emis_phase = false;
 #pragma unroll
@@ -2118,6 +2221,15 @@ __global__ __launch_bounds__(kBlock, SKY ? ((BIG && STATS && ENV) ? PT_BIG_WAVES
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler (guide, G16)
         if (lane == 0) __hip_atomic_store(&a.sched[1 + tile], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef PT_ADAPT_COUNT
+    if (a.stats && lane == 0) {
+        atomicAdd(&a.stats[0], static_cast<unsigned long long>(c_rays));
+        atomicAdd(&a.stats[6], static_cast<unsigned long long>(c_one));
+        atomicAdd(&a.stats[7], static_cast<unsigned long long>(c_two));
+        atomicAdd(&a.stats[1], static_cast<unsigned long long>(c_seg1));
+        atomicAdd(&a.stats[5], static_cast<unsigned long long>(c_seg2));
+    }
+#endif
 #ifdef PT_VERIFY_SHIPPED
     if (a.stats && lane == 0) {
         atomicAdd(&a.stats[9], static_cast<unsigned long long>(v_checked));
@@ -2279,6 +2391,7 @@ hipError_t integrator_waves_per_cu(const RenderArgs &, int *waves) {
 void integrator_plan_tiles(RenderArgs &args, int, int) {   // (the instrumented code object holds the wide variant only)
     const int rays = (!args.sky && !args.stats) ? ((args.big != 0) ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
     args.narrow = 0;
+    args.adapt_pool = 0;
     args.blocks_x = (args.width + kTileW * rays - 1) / (kTileW * rays);
     args.n_tiles = static_cast<uint32_t>(args.blocks_x) * static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
 }
@@ -2289,7 +2402,7 @@ bool launch_with_stats(const RenderArgs &args) {
 #if defined(PT_PHASE_TIMERS) || defined(PT_VERIFY_BRUTE)
     (void)args;
     return true;
-#elif defined(PT_VERIFY_SHIPPED)
+#elif defined(PT_VERIFY_SHIPPED) || defined(PT_ADAPT_COUNT)
     (void)args;
     return false;   // the instantiations a caller without pt_render_stats gets; args.stats only receives the verdict
 #else
@@ -2312,8 +2425,12 @@ void with_instantiation(const RenderArgs &args, F &&f) {
             if constexpr (!B) {
                 // adaptive sampling on: the instantiation that compacts sparse passes (not built with the rare envelope test:
                 // one more spilled register there)
-                if (args.error >= 0.0f && !args.may_leave_envelope) {
-                    f(integrate_kernel<false, false, false, false, false, true>, 20);
+                if (args.adapt_pool == 4) {
+                    f(integrate_kernel<false, false, false, false, false, 4>, 21);
+                    return;
+                }
+                if (args.adapt_pool == 2) {
+                    f(integrate_kernel<false, false, false, false, false, 2>, 20);
                     return;
                 }
             }
@@ -2353,18 +2470,26 @@ void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
     const uint32_t rows = static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
     int rays = (!sky && !stats) ? (big ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
     args.narrow = 0;
+    args.adapt_pool = 0;
+    int tile_px = rays;   // tile width in 8-pixel column blocks
     if (rays > 1) {
         const uint32_t wide_tiles = static_cast<uint32_t>((args.width + kTileW * rays - 1) / (kTileW * rays)) * rows;
         // one and a half rounds of its waves (measured, profiles/r03_ab_logs.txt ab53: 7 200 tiles -19 %, 8 160 tiles +3 %, 16 200 +6.6 %)
         uint32_t min_tiles = static_cast<uint32_t>(cu_count) * 4u * static_cast<uint32_t>(PT_WAVES_PER_SIMD - 1) * 3u / 2u;
-        if (force == 1) min_tiles = 0xFFFFFFFFu;   // (test builds: always 8 x 8 / always 16 x 8)
-        if (force == 2) min_tiles = 0;
+        if (force == 1) min_tiles = 0xFFFFFFFFu;   // (test builds: always 8 x 8 / always 16 x 8 / always 32 x 8 with adaptive sampling on)
+        if (force == 2 || force == 3) min_tiles = 0;
         if (wide_tiles < min_tiles) {
-            rays = 1;
+            rays = tile_px = 1;
             args.narrow = 1;
+        } else if (!big && args.error >= 0.0f && !args.may_leave_envelope && args.pass_begin >= 0 && args.pass_begin + args.pass_count <= kMaxBatchPass) {
+            // adaptive sampling on: the instantiations that run batches (not built with the rare envelope test: one more spilled
+            // register there) -- over 32 x 8 tiles if there are enough of those as well, else over 16 x 8 tiles
+            const uint32_t pool4_tiles = static_cast<uint32_t>((args.width + kTileW * 4 - 1) / (kTileW * 4)) * rows;
+            args.adapt_pool = (force != 2 && pool4_tiles >= min_tiles) ? 4 : 2;
+            tile_px = args.adapt_pool;
         }
     }
-    args.blocks_x = (args.width + kTileW * rays - 1) / (kTileW * rays);
+    args.blocks_x = (args.width + kTileW * tile_px - 1) / (kTileW * tile_px);
     args.n_tiles = static_cast<uint32_t>(args.blocks_x) * rows;
 }
 
@@ -2372,7 +2497,7 @@ void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
 // calculation (registers, LDS, launch bounds): the scheduler's count of wave slots.  Asked once per instantiation and device.
 hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves) {
     constexpr int kDevices = 16;
-    static std::atomic<int> cache[kDevices][21];   // 0 = not asked yet
+    static std::atomic<int> cache[kDevices][22];   // 0 = not asked yet
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -45,6 +45,7 @@ struct RenderArgs {
     float k1, k2, a_max, m0, m0_quad, t_guard;   // cull margins (pt_scene.hpp: CullConstants)
     int32_t blocks_x;                   // ceil(width / tile width of the instantiation launched)
     int32_t narrow;                     // 1: the statistics-free small-scene kernel runs its one-pixel-per-lane variant (8 x 8 tiles)
+    int32_t adapt_pool;                 // 2 / 4: the adaptive-sampling instantiation over 16 x 8 / 32 x 8 tiles runs (batches); 0: none
     uint32_t *sched;                    // [0] ticket counter, [1 + tile] chunks of that tile already published; zeroed per launch
     uint32_t n_tiles, n_chunks;         // work items = n_tiles * n_chunks, chunk-major
     int32_t chunk_passes;               // passes per chunk; 0 = geometric chunks (see the kernel)
@@ -65,8 +66,8 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);
 // waves of the instantiation such a launch runs that one compute unit holds at a time (runtime occupancy query, cached)
 hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves);
 // cuts the launch's row band (width, row_begin, row_end, scene, stats already set) into the tiles of the instantiation it will
-// run: fills narrow, blocks_x and n_tiles
-// (force: 0 = by tile count, 1 = always 8 x 8 tiles, 2 = always the widest: test builds)
+// run: fills narrow, adapt_pool, blocks_x and n_tiles
+// (force: 0 = by tile count, 1 = always 8 x 8 tiles, 2 = always 16 x 8, 3 = always 16 x 8 and 32 x 8 with adaptive sampling on: test builds)
 void integrator_plan_tiles(RenderArgs &args, int cu_count, int force = 0);
 // diagnostic: both forms of the box tree's child test on (node, ray, t_best) items; out[2 i] = float form, out[2 i + 1] = half-precision form
 hipError_t launch_box_masks(const BvhNode *d_nodes, const float *d_rays, const float *d_t_best, float err, int n, uint32_t *d_out, hipStream_t stream);

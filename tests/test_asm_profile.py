@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "tools", "asm_profile.py")
-K = "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE"
+K = "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE"
 
 ASM = f"""\t.file\t0 "/x" "pt_kernels.hip"
 \t.text

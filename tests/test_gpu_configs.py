@@ -277,6 +277,7 @@ def test_regeneration_keeps_the_lanes_busy(tmp_path):
     for setting in (1, 64):
         H_.pt_test_set_mutation(b"reset", 0.0)
         H_.pt_test_set_mutation(b"regen_min_dead", float(setting))
+        H_.pt_test_set_mutation(b"items_per_slot", -1.0)      # (the scheduler's long chunks: a frame of this size would get short ones, each with a tail)
         try:
             g = pt.Scene.load_obj(d, "TorOpen.obj", device=0, library=H_)
             g.set_skybox(d + "sky.bmp")

@@ -66,7 +66,7 @@ def test_frame_bit_exact(gpu_scene, oracle_scene, W, H, spp, mrr, kw):
 SHIPPED_CASES = [(1, 1, 40, 8, {}), (7, 3, 30, 8, {}), (8, 9, 20, 8, {}), (9, 8, 20, 3, {}), (15, 5, 16, 8, {}), (16, 8, 16, 8, {}),
                  (17, 33, 8, 8, {"error": 0.001}), (31, 7, 12, 2, {}), (37, 19, 9, 8, {}), (96, 64, 6, 8, {}),
                  (40, 24, 24, 8, {"error": 0.5}), (104, 50, 12, 8, {"error": 0.001, "seed": 7}), (250, 130, 5, 8, {"eps": 1e-3}),
-                 # adaptive sampling deep into the passes where it bites: the two-pixel kernel compacts sparse passes
+                 # adaptive sampling deep into the passes where it bites: the two-pixel kernel runs batches of the tile's pixels
                  (48, 40, 40, 8, {"error": 0.02}), (33, 17, 64, 4, {"error": 0.005, "seed": 3}), (64, 16, 30, 8, {"error": 0.5, "seed": 9}),
                  (16, 8, 50, 8, {"error": 0.01})]
 
@@ -83,8 +83,9 @@ def hooks_lib():
 def test_statistics_free_instantiation_bit_exact(gpu_scene, oracle_scene, hooks_lib, models_dir, W, H, spp, mrr, kw):
     rs, rs2, rc, _ = O.render(oracle_scene, W, H, spp, mrr, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, **kw)
     # The library picks 16 x 8 tiles (two pixels per lane) only when they fill the chip, so frames of this size would run the
-    # 8 x 8 variant: both variants are pinned in turn through the test-hook build (same kernels), then the product's own choice.
-    for width_mode in (2.0, 1.0):
+    # 8 x 8 variant: the variants are pinned in turn through the test-hook build (same kernels; 3 = 16 x 8, and 32 x 8 for the
+    # batches of adaptive launches), then the product's own choice.
+    for width_mode in (3.0, 2.0, 1.0):
         hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
         try:
             h = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=hooks_lib)
@@ -362,13 +363,46 @@ def test_pinned_host_buffers_through_the_abi(gpu_scene):
     L.pt_host_free(None)
 
 
+@pytest.mark.parametrize("W,H,kw", [(960, 540, {}), (960, 540, {"error": 0.001}), (1366, 768, {"error": 0.001}), (1920, 1080, {"error": 0.001})],
+                         ids=["960x540", "960x540-adaptive", "1366x768-adaptive", "1080p-adaptive"])
+def test_the_schedulers_chunk_schemes_render_the_same_frame(hooks_lib, models_dir, W, H, kw):
+    """Between about one and two pixel tiles per wave slot a launch's passes are cut into EQUAL chunks (pt_capi.cpp:
+    enqueue_render), elsewhere into 3/4 - of - the - rest chunks; a tile's chunks run in order on whichever wave takes them, each
+    starting from the accumulators the previous one published.  The frames here fall in that range on a 256-CU device (8 x 8 tiles at
+    960 x 540, 16 x 8 at 1366 x 768, the 32 x 8 batch tiles of an adaptive 1080p launch): the library's own choice, the 3/4 scheme
+    alone (hook < 0), and equal chunks of other sizes must all give the same bits -- the statistics instantiation's too, whose report
+    shows that the choice really was equal chunks."""
+    spp = 32
+    frames, chunks = {}, {}
+    try:
+        for ips in (0.0, -1.0, 8.0, 40.0):
+            hooks_lib.pt_test_set_mutation(b"reset", 0.0)
+            hooks_lib.pt_test_set_mutation(b"items_per_slot", ips)
+            h = pt.Scene.load_obj(models_dir, "Tor.obj", device=0, library=hooks_lib)
+            s, s2, c, _ = h.render_host(W, H, spp, 8, want_stats=False, **kw)
+            frames[ips] = (s.copy(), s2.copy(), c.copy())
+            if ips <= 0.0:
+                t, t2, tc, st = h.render_host(W, H, spp, 8, want_stats=True, **kw)
+                chunks[ips] = st["n_chunks"]
+                assert np.array_equal(tc, c) and _same(t, s) and _same(t2, s2)
+            h.close()
+    finally:
+        hooks_lib.pt_test_set_mutation(b"reset", 0.0)
+    for ips, f in frames.items():
+        assert np.array_equal(f[2], frames[0.0][2]) and _same(f[0], frames[0.0][0]) and _same(f[1], frames[0.0][1]), ips
+    assert frames[0.0][2].sum() > 0
+    assert chunks[-1.0] == 2, chunks                      # 32 passes: 24 + 8
+    if (W, H) == (960, 540):
+        assert chunks[0.0] >= 4, chunks                   # 8 160 tiles of 8 x 8 on 5 120 slots: equal chunks of a few passes
+
+
 @pytest.mark.parametrize("instances,W,H,spp,kw", [(3, 48, 32, 200, {"error": 0.05}), (6, 32, 24, 160, {"error": 0.2, "seed": 5})],
                          ids=["x3", "x6"])
 def test_compacted_adaptive_passes_on_scenes_with_several_trees(tmp_path, hooks_lib, instances, W, H, spp, kw):
     """Adaptive sampling, two pixels per lane, on small scenes with several sphere-tree clusters (Tor.obj's torus 3 and 6 times
-    in the room: 782 / 1 550 triangles): passes with at most 64 traced pixels per tile run compacted (pt_kernels.hip
-    "Compaction"), a lane then traces another lane's pixel through every cluster loop, root round and tree walk -- the
-    oracle's bits all the same, for both tile widths."""
+    in the room: 782 / 1 550 triangles): the tile's pixels run in batches, each pixel at its own next pass (pt_kernels.hip
+    "Batches"), a lane then traces another lane's pixel through every cluster loop, root round and tree walk -- the
+    oracle's bits all the same, for every tile width."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import make_replicated_scene as M
@@ -377,7 +411,7 @@ def test_compacted_adaptive_passes_on_scenes_with_several_trees(tmp_path, hooks_
     o = O.Scene.load(d, "r.obj")
     rs, rs2, rc, rst = O.render(o, W, H, spp, 8, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, **kw)
     assert rst["samples_traced"] < 0.8 * W * H * spp        # the adaptive skip really bites (about 60 % of the pixels end up skipping)
-    for width_mode in (2.0, 1.0):
+    for width_mode in (3.0, 2.0, 1.0):
         hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
         hooks_lib.pt_test_set_mutation(b"big_threshold", 16384.0)      # (1 550 triangles are beyond the shipped switch: keep the sphere trees)
         try:
@@ -439,7 +473,7 @@ def test_material_counts_around_the_lds_copy(tmp_path, hooks_lib, n_mats):
         W, H, spp = 48, 24, 40
         rs, rs2, rc, _ = O.render(o, W, H, spp, 8, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, **kw)
         assert rc.sum() > 0
-        for width_mode in (2.0, 1.0):
+        for width_mode in (3.0, 2.0, 1.0):
             hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
             try:
                 h = pt.Scene.load_obj(d, "m.obj", device=0, library=hooks_lib)

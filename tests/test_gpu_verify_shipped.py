@@ -63,10 +63,11 @@ def test_every_segment_of_config1_on_the_shipped_instantiation(models_dir, vlib)
 
 
 @pytest.mark.parametrize("mrr", [1, 2, 3])
-@pytest.mark.parametrize("tile_width", [1, 2], ids=["8x8", "16x8"])
+@pytest.mark.parametrize("tile_width", [1, 2, 3], ids=["8x8", "16x8", "32x8"])
 def test_short_paths_and_adaptive_sampling(models_dir, vlib, mrr, tile_width):
     """-MRR 1: every segment is a last segment (only camera rays that see the light contribute).  A frame of this size would
-    run the 8 x 8-tile variant of the statistics-free kernel; both variants are pinned in turn."""
+    run the 8 x 8-tile variant of the statistics-free kernel; the variants are pinned in turn (adaptive sampling on: the batch
+    kernels over 16 x 8 and 32 x 8 tiles)."""
     vlib.pt_test_set_mutation(b"tile_width", float(tile_width))
     try:
         st = _check(vlib, models_dir, "Tor.obj", 640, 360, 24, mrr, error=0.001)
@@ -75,25 +76,25 @@ def test_short_paths_and_adaptive_sampling(models_dir, vlib, mrr, tile_width):
     assert st["verify_mismatches"] == 0
 
 
+@pytest.mark.parametrize("tile_width", [2, 3], ids=["16x8", "32x8"])
 @pytest.mark.parametrize("error,spp", [(0.001, 160), (0.005, 64), (0.5, 32)])
-def test_compacted_passes_of_adaptive_sampling(models_dir, vlib, error, spp):
-    """Adaptive sampling on, two pixels per lane: a pass in which at most 64 of a tile's 128 pixels are traced runs compacted
-    (second pixels moved into other lanes' free first slots, pt_kernels.hip "Compaction").  Every segment of such a frame is
-    checked, the frame is the frame of the other instantiations (_check), and the passes really were compacted: this build
-    counts them in the field the statistics-free instantiation has no other use for."""
-    vlib.pt_test_set_mutation(b"tile_width", 2.0)
+def test_batches_of_adaptive_sampling(models_dir, vlib, error, spp, tile_width):
+    """Adaptive sampling on, two ray slots per lane: the tile's pixels (128 or 256) run in batches, each pixel at its own next
+    pass, a chosen pixel on whichever lane its rank in the batch gives it (pt_kernels.hip "Batches").  Every segment of such a
+    frame is checked, the frame is the frame of the other instantiations (_check), and pixels really did move: this build counts
+    the batches in which some slot traced a pixel that is not its own, in the field the statistics-free instantiation has no other
+    use for."""
+    vlib.pt_test_set_mutation(b"tile_width", float(tile_width))
     try:
         st = _check(vlib, models_dir, "Tor.obj", 480, 272, spp, 8, error=error, seed=11)
-        compacted = st["partial_commit_rounds"]
+        moved = st["partial_commit_rounds"]
         vlib.pt_test_set_mutation(b"tile_width", 1.0)
         narrow = _check(vlib, models_dir, "Tor.obj", 480, 272, spp, 8, error=error, seed=11)
     finally:
         vlib.pt_test_set_mutation(b"reset", 0.0)
     assert st["verify_mismatches"] == 0 and narrow["verify_mismatches"] == 0
     assert st["verify_checked"] == narrow["verify_checked"]
-    # (644 compacted tile-passes at -ERR 0.001 x 96 spp; with a loose threshold most pixels stop at pass 11 and few tiles are left
-    # with traced second pixels at all: 48 at -ERR 0.5 x 32 spp; none, ever, with 8 x 8 tiles)
-    assert compacted > 30 and narrow["partial_commit_rounds"] == 0, compacted
+    assert moved > 30 and narrow["partial_commit_rounds"] == 0, moved
 
 
 def test_every_segment_of_the_x64_replica_on_the_shipped_instantiation(tmp_path, vlib):

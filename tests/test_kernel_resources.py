@@ -33,14 +33,17 @@ def usage():
     return out
 
 
-# mangled name -> (what, waves per SIMD at least, LDS bytes at most)
+# mangled name -> (what, waves per SIMD at least, LDS bytes at most).  gfx950 hands out its 160 KB of LDS in granules of 1 280 bytes
+# (the 32 x 8 adaptive kernel at 7 888 B lost its fifth wave per SIMD to that -- a sixth granule is 7 680 B -- although 20 x 7 888 <
+# 160 K: +13 % frame time, profiles/r04_ab_logs.txt adapt2): 20 waves per CU leave 6 granules each, 24 waves 5.
 HOT = {
-    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("small scenes, two pixels per lane (the headline kernel)", 5, 8192),
-    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb1EEEvNS_10RenderArgsE": ("the same with adaptive sampling on (compacts sparse passes)", 5, 8192),
-    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb1ELb0EEEvNS_10RenderArgsE": ("small scenes, one pixel per lane (small launches)", 6, 6826),
-    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 6, 6826),
-    "_ZN2pt16integrate_kernelILb1ELb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("small scenes under a skybox (path regeneration)", 5, 8192),
-    "_ZN2pt16integrate_kernelILb1ELb1ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE": ("big scenes under a skybox", 5, 8192),
+    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE": ("small scenes, two pixels per lane (the headline kernel)", 5, 7680),
+    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELi2EEEvNS_10RenderArgsE": ("the same with adaptive sampling on (batches over 16 x 8 tiles)", 5, 7680),
+    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELi4EEEvNS_10RenderArgsE": ("the same over 32 x 8 tiles", 5, 7680),
+    "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb1ELi0EEEvNS_10RenderArgsE": ("small scenes, one pixel per lane (small launches)", 6, 6400),
+    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 6, 6400),
+    "_ZN2pt16integrate_kernelILb1ELb0ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE": ("small scenes under a skybox (path regeneration)", 5, 7680),
+    "_ZN2pt16integrate_kernelILb1ELb1ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE": ("big scenes under a skybox", 5, 7680),
 }
 
 

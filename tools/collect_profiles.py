@@ -92,9 +92,9 @@ def main():
     ks = max(glob.glob(os.path.join(G, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     shutil.copy(ks, os.path.join(P, f"{t}_kernel_stats.csv"))
     out = {}
-    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,false,false,false,false,false>)", True),
-                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,true,false,false,false,false>)", True),
-                               ("pmc_sky", "Tor.obj without its back wall under a sky bitmap, 1920x1080x256spp (pt_render -SKYBOX -BENCH_STEPS 1, timed kernel integrate_kernel<true,false,false,false,false,false>, path regeneration)", True)):
+    for name, label, timed in (("pmc_tor", "Tor.obj 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,false,false,false,false,0>)", True),
+                               ("pmc_x64", "replicated scene x64, 16398 triangles, 1920x1080x256spp (pt_render -BENCH_STEPS 1, timed kernel integrate_kernel<false,true,false,false,false,0>)", True),
+                               ("pmc_sky", "Tor.obj without its back wall under a sky bitmap, 1920x1080x256spp (pt_render -SKYBOX -BENCH_STEPS 1, timed kernel integrate_kernel<true,false,false,false,false,0>, path regeneration)", True)):
         m = detail(os.path.join(G, name), timed)
         if m:
             out[label] = m
@@ -117,8 +117,8 @@ def main():
     import subprocess
     import sys
     mp = os.path.join(ROOT, "path-tracing_amd", "lib", "blockprof", "map.json")
-    for scene, kern in (("tor", "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE"),
-                        ("x64", "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELb0EEEvNS_10RenderArgsE")):
+    for scene, kern in (("tor", "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE"),
+                        ("x64", "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE")):
         cnt = os.path.join(G, f"blockprof_{scene}.{kern}.txt")
         log = os.path.join(G, f"blockprof_{scene}.log")
         if not (os.path.exists(cnt) and os.path.exists(mp) and os.path.exists(log)):
