@@ -1458,7 +1458,7 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 #endif
 constexpr int kMaxBatchPass = 32766;   // adaptive instantiations: a pixel's next pass (at most one past the launch's last) << 1 | a flag in 16 bits
 #ifndef PT_ADAPT_TWO_AT
-#define PT_ADAPT_TWO_AT 120   // adaptive kernel: pixels of a tile (of 128) with a pass to run from which a batch takes them all, two per lane
+#define PT_ADAPT_TWO_AT 100   // adaptive kernels: pixels with a pass to run from which a batch takes up to 128, two per lane (80 ... 112 within 1 %, adapt3)
 #endif
 #ifndef PT_BIG_RAYS_PER_LANE
 #define PT_BIG_RAYS_PER_LANE 1   // the same for the statistics-free, skybox-free big-scene kernel

@@ -27,7 +27,7 @@ L.pt_test_set_mutation(b"reset", 0.0)
 models = os.path.join(ROOT, "models") + "/"
 jobs = [("configs[2] Tor.obj 1920x1080x1024spp", models, "Tor.obj", 1920, 1080, 1024, -1.0),
         ("configs[3] Tor.obj 3840x2160x256spp", models, "Tor.obj", 3840, 2160, 256, -1.0)]
-if shipped:   # the reference's default -ERR 0.001: the two-pixel kernel's adaptive instantiation, sparse passes compacted
+if shipped:   # the reference's default -ERR 0.001: the two-pixel kernel's adaptive instantiations (batches of the tile's pixels, 32 x 8 tiles at this size)
     jobs.append(("Tor.obj 1920x1080x512spp -ERR 0.001", models, "Tor.obj", 1920, 1080, 512, 0.001))
 d = tempfile.mkdtemp() + "/"
 for n, spp in ((64, 32), (195, 16)):
@@ -49,7 +49,7 @@ for name, dd, obj, W, H, spp, err in jobs:
         s.set_skybox(d + "sky.bmp")
     t = time.perf_counter()
     st = s.render_host(W, H, spp, 8, error=err)[3]
-    extra = f", {st['partial_commit_rounds']} compacted tile-passes" if shipped and err >= 0 else ""
+    extra = f", {st['partial_commit_rounds']} batches in which a pixel ran on another lane" if shipped and err >= 0 else ""
     print(f"{name}: {st['verify_checked']} segments checked against all {st['n_triangles']} triangles, "
           f"{st['verify_mismatches']} mismatches{extra}, {time.perf_counter() - t:.1f} s", flush=True)
     s.close()
