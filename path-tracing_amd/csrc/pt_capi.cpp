@@ -17,6 +17,7 @@
 static int g_items_per_slot = 0;
 static int g_force_tile_width = 0;   // 1 = always 8 x 8 tiles, 2 = always 16 x 8 where the instantiation has them, 3 = the same and 32 x 8 for adaptive launches, 0 = by tile count
 static int g_regen_min_dead = 0;     // test build: overrides RenderArgs::regen_min_dead (0 = the library's)
+static int g_chunk_min = 0;          // test build: passes the scheduler's last geometric chunk holds at least (0 = the library's)
 #endif
 
 namespace ptc {
@@ -286,7 +287,9 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
     const uint32_t n_tiles = a.n_tiles;
     // Scheduler: cut the pass range into chunks so that the tail of the launch is balanced with small work items.  A tile's
     // chunks run in order and each re-reads and re-writes the tile's accumulators, so there should be few of them: chunk c
-    // takes 3/4 of the passes that are left (256 passes: 192 + 48 + 16), the last one at least 4 and less than 32.
+    // takes 3/4 of the passes that are left, down to single passes (256 passes: 192 + 48 + 12 + 3 + 1; until round 4 the last
+    // chunk held 8 to 31 passes -- 192 + 48 + 16 -- and launches below 32 passes were one chunk: 16 passes at 1080p 5.26 -> 4.71 ms,
+    // 64 passes 18.81 -> 18.20, 256 passes 72.70 -> 72.08, profiles/r04_ab_logs.txt chunks2).
     // Wave slots of the chip FOR THE INSTANTIATION THIS LAUNCH RUNS: its occupancy is the compiler's and the LDS budget's
     // business, asked from the runtime once per instantiation instead of assumed.
     int waves_per_cu = 24;
@@ -294,8 +297,12 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
     const uint32_t slots = static_cast<uint32_t>(scene->cu_count) * static_cast<uint32_t>(std::max(1, waves_per_cu));
     uint32_t n_chunks = 1;
     int32_t chunk_passes = 0;
+    int chunk_min = 1;
+#ifdef PT_TEST_HOOKS
+    if (g_chunk_min > 0) chunk_min = g_chunk_min;
+#endif
     if (n_tiles >= slots / 2u)
-        while (n_chunks < 6u && (p->pass_count >> (2u * n_chunks)) >= 8) ++n_chunks;
+        while (n_chunks < 6u && (p->pass_count >> (2u * n_chunks)) >= chunk_min) ++n_chunks;
     // Between about one and two tiles per wave slot the first of those chunks is too coarse -- all tiles' 3/4 of the passes: the
     // chip runs one full round of them and a second one half empty.  There the pass range is cut into EQUAL chunks, 8 to 32
     // work items per wave slot: Tor.obj 1366 x 768 x 256 spp 47.5 -> 40.2 ms, 960 x 540 25.7 -> 21.9 ms, and the 32 x 8 tiles of
@@ -1126,8 +1133,9 @@ int pt_test_set_mutation(const char *family, double value) {
     if (!family) return PT_ERR_INVALID_ARGUMENT;
     const std::string f = family;
     pt::CullMutation &m = pt::g_cull_mutation;
-    if (f == "reset") { m = pt::CullMutation(); g_items_per_slot = 0; g_force_tile_width = 0; g_regen_min_dead = 0; }
+    if (f == "reset") { m = pt::CullMutation(); g_items_per_slot = 0; g_force_tile_width = 0; g_regen_min_dead = 0; g_chunk_min = 0; }
     else if (f == "regen_min_dead") g_regen_min_dead = static_cast<int>(value);
+    else if (f == "chunk_min") g_chunk_min = static_cast<int>(value);
     else if (f == "sphere_r2") m.sphere_r2 = value;
     else if (f == "m0") m.m0 = value;
     else if (f == "k12") m.k12 = value;

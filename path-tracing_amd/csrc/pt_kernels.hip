@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
     const uint32_t tile = item % a.n_tiles, chunk = item / a.n_tiles;
     // chunk_passes > 0: equal chunks.  chunk_passes == 0: chunk c covers passes [P - (P >> 2c), P - (P >> 2(c+1))) of the launch's P
     // (3/4 of what is left each time, the last chunk takes the rest): the tail of the launch is balanced with small items while a
-    // tile's accumulators make few round trips to memory (3 chunks at 256 passes: 192 + 48 + 16).
+    // tile's accumulators make few round trips to memory (5 chunks at 256 passes: 192 + 48 + 12 + 3 + 1).
     int pass_first, pass_last;
     if (a.chunk_passes > 0) {
         pass_first = a.pass_begin + static_cast<int>(chunk) * a.chunk_passes;
@@ -1593,7 +1593,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
         if constexpr (ADAPT) {
             // (the answers of this instantiation live in LDS, by pixel: below)
         } else if constexpr (!kAccInLds) {
-            if (in_image[k]) {
+            if (in_image[k] && a.error >= 0.0f) {   // (adaptive sampling off: nobody asks, and a work item need not read its tile at all)
                 const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + x[k];
                 lowvar[k] = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
             }
