@@ -297,7 +297,11 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
     const uint32_t slots = static_cast<uint32_t>(scene->cu_count) * static_cast<uint32_t>(std::max(1, waves_per_cu));
     uint32_t n_chunks = 1;
     int32_t chunk_passes = 0;
-    int chunk_min = 1;
+    // (launches that fill a statistics block keep the old floor of 8: every work item ends with a dozen atomic adds to the same
+    // few words, and 65 000 more items cost the 16-pass 1080p frame 6.7 -> 11.2 ms)
+    // (and the regenerating kernels under a sky, where a chunk's end is a tail of idle lanes; the 8 x 8 kernel with its accumulators
+    // in LDS stops at 2: chunks2)
+    int chunk_min = (want_stats || a.sky != nullptr) ? 8 : a.narrow ? 2 : 1;
 #ifdef PT_TEST_HOOKS
     if (g_chunk_min > 0) chunk_min = g_chunk_min;
 #endif
