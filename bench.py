@@ -610,7 +610,6 @@ def main():
         c2_traffic = (pmc_c2["FETCH_SIZE"] + pmc_c2["WRITE_SIZE"]) * 1024.0 if pmc_c2 and "FETCH_SIZE" in pmc_c2 and "WRITE_SIZE" in pmc_c2 else None
         c2["hbm"] = {"algorithmic_bytes": c2_algo, "traffic_bytes": c2_traffic,
                      "traffic_over_algorithmic": c2_traffic / c2_algo if c2_traffic else None,
-                     "chunks_per_tile": int(c2_st.get("n_chunks", 0)) or None,
                      "achieved": (c2_traffic or c2_algo) / (c2["kernel_ms"] * 1e-3) / 1e9 if c2["kernel_ms"] > 0 else None,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": ((c2_traffic or c2_algo) / (c2["kernel_ms"] * 1e-3) / 1e9) / PEAK_HBM_GBS if c2["kernel_ms"] > 0 else None,
@@ -677,7 +676,6 @@ def main():
         samples_per_step = W * H * args.spp
         seg = float(frame_stats["segments"])
         kms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        n_chunks = max(1, frame_stats.get("n_chunks", 1))
         # W*H*28 B of accumulators in and out per render call + the scene once
         algo_bytes = npx * 28 * 2 + n_tri * 56
         if pmc is None and world == 1 and args.pmc != "off":
@@ -732,9 +730,8 @@ def main():
                          "flop_per_test": FLOP_PER_TEST,
                          "hbm": {"algorithmic_bytes": algo_bytes, "traffic_bytes": traffic,
                                  "traffic_over_algorithmic": traffic / algo_bytes if traffic else None,
-                                 "chunks_per_tile": n_chunks,
-                                 "why": "the timed kernel (two pixels per lane) leaves the accumulators in memory: read once per pass-range chunk for the "
-                                        "adaptive-sampling state, read-modify-written (three sparse cache lines) when a path reaches an emitter",
+                                 "why": "the timed kernel (two pixels per lane) leaves the accumulators in memory: read-modify-written (three sparse cache "
+                                        "lines in and out) when a path reaches an emitter, 1 % of the samples; with adaptive sampling off nothing else touches them",
                                  "achieved": (traffic or algo_bytes) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": ((traffic or algo_bytes) / (kms * 1e-3) / 1e9) / PEAK_HBM_GBS if kms > 0 else 0.0}},

@@ -2362,7 +2362,7 @@ hipError_t launch_integrator(const RenderArgs &args0, hipStream_t stream) {
     RenderArgs args = args0;
     args.blockprof = d_cnt;
     char name[128];
-    std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dELb0ELb0EEEvNS_10RenderArgsE", args.sky ? 1 : 0,
+    std::snprintf(name, sizeof name, "_ZN2pt16integrate_kernelILb%dELb%dELb%dELb%dELb0ELi0EEEvNS_10RenderArgsE", args.sky ? 1 : 0,
                   (args.big != 0) ? 1 : 0, args.stats ? 1 : 0, args.may_leave_envelope ? 1 : 0);
     hipFunction_t f;
     e = hipModuleGetFunction(&f, mod, name);
