@@ -89,6 +89,12 @@ struct SmallQueues2 { static constexpr int kNodeStack = PT_SMALL2_NODES, kPairQu
 #define PT_SKY_WAVES (PT_WAVES_PER_SIMD - 1)
 #endif
 struct BigQueues { static constexpr int kNodeStack = PT_BIG_NODES, kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };
+// the box-tree kernel's adaptive instantiations keep one 16-bit word per pixel of their tile (128 / 256 pixels) in LDS: the node stack
+// gives up that much, so that the wave stays within five 1 280-byte granules (six waves per SIMD)
+#ifndef PT_BIG_ADAPT_NODES
+#define PT_BIG_ADAPT_NODES(pixels_per_lane) ((PT_BIG_NODES + 46 - 32 * (pixels_per_lane)) > 64 ? (PT_BIG_NODES + 46 - 32 * (pixels_per_lane)) : 64)   // (the tiny-queue test build)
+#endif
+template <int OWN> struct BigQueuesAdapt { static constexpr int kNodeStack = PT_BIG_ADAPT_NODES(OWN), kPairQueue = PT_BIG_PAIRS, kFiltered = PT_BIG_FILTERED; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Counter RNG (layout shared with the CPU oracle; see DESIGN.md "Counter RNG")
@@ -1481,7 +1487,7 @@ template <bool SKY, bool BIG, bool STATS, bool ENV, bool NARROW = false, int ADA
 __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NARROW>())) void integrate_kernel(const RenderArgs a) {
     static_assert(!NARROW || (!SKY && !STATS), "only the statistics-free, skybox-free kernels have a narrow variant");
     constexpr int R = NARROW ? 1 : rays_per_lane<SKY, BIG, STATS>();   // pixels per lane: the wave's tile is kTileW * R x kTileH
-    static_assert(ADAPT == 0 || ((ADAPT == 2 || ADAPT == 4) && R == 2 && !BIG && !STATS && !SKY), "batches of the tile's pixels, two ray slots per lane; a pixel's number takes 8 bits");
+    static_assert(ADAPT == 0 || ((ADAPT == 2 || ADAPT == 4) && (R == 2 || BIG) && !STATS && !SKY), "batches of the tile's pixels (a pixel's number takes 8 bits): the two-pixel kernel and the box-tree kernel");
     // REGEN = path regeneration: a lane whose path has ended starts its pixel's NEXT pass at once instead of idling until the
     // longest path of the wave is done.  The skybox instantiations run this way: a scene with a skybox is an open scene, most
     // paths end on their first or second segment (scene.cpp:125-155: a miss ends the path) -- Tor.obj without its back wall has
@@ -1494,7 +1500,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
     static_assert(!REGEN || !ADAPT, "the compacting instantiation keeps the pass loop");
     constexpr int kOwn = ADAPT ? ADAPT : R;   // pixels of the tile per lane: pixel j of the tile = column (j % 8) + 8 (j / 64), row (j % 64) / 8
     constexpr int kTW = kTileW * kOwn;
-    __shared__ WaveLds<std::conditional_t<BIG, BigQueues, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R, ADAPT> lds;   // one wave per workgroup: all wave-private
+    __shared__ WaveLds<std::conditional_t<BIG, std::conditional_t<ADAPT != 0, BigQueuesAdapt<ADAPT>, BigQueues>, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R, ADAPT> lds;   // one wave per workgroup: all wave-private
 
     const int lane = threadIdx.x;
     if constexpr (decltype(lds)::kMatCache > 0) {
@@ -1760,7 +1766,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
                 behind = min(behind, pend[kb] ? np[kb] : ~0u);
             }
             if (n_pend == 0) break;
-            const uint32_t quota = n_pend >= static_cast<uint32_t>(PT_ADAPT_TWO_AT) ? 128u : 64u;
+            const uint32_t quota = (R == 2 && n_pend >= static_cast<uint32_t>(PT_ADAPT_TWO_AT)) ? 128u : 64u;   // (the box-tree kernel has one ray slot per lane)
             if (n_pend > quota) {
                 const uint32_t m = wave_min(behind);
                 uint32_t at_a = 0, at_b = 0, rank_a[kOwn], rank_b[kOwn];
@@ -1799,7 +1805,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
                 if (traced[k]) jobs |= lds.pairs[le + 64u * k] << (8 * k);
             }
 #ifdef PT_VERIFY_SHIPPED
-            if (__any((traced[0] && (jobs & 0xFFu) != le) || (traced[1] && (jobs >> 8) != le + 64u))) ++v_compacted;
+            if (__any((traced[0] && (jobs & 0xFFu) != le) || (traced[R - 1] && R == 2 && (jobs >> 8) != le + 64u))) ++v_compacted;
 #endif
             wave_sync();   // (the list was in the pair queue: read before the search fills that)
 #pragma unroll
@@ -2423,8 +2429,8 @@ void with_instantiation(const RenderArgs &args, F &&f) {
                 return;
             }
             if constexpr (!B) {
-                // adaptive sampling on: the instantiation that compacts sparse passes (not built with the rare envelope test:
-                // one more spilled register there)
+                // adaptive sampling on: the instantiations that run batches (not built with the rare envelope test: one more
+                // spilled register there)
                 if (args.adapt_pool == 4) {
                     f(integrate_kernel<false, false, false, false, false, 4>, 21);
                     return;
@@ -2433,6 +2439,16 @@ void with_instantiation(const RenderArgs &args, F &&f) {
                     f(integrate_kernel<false, false, false, false, false, 2>, 20);
                     return;
                 }
+            }
+        }
+        if constexpr (!S && !T && B) {   // the box-tree kernel with adaptive sampling on: batches over 16 x 8 / 32 x 8 tiles, one ray slot per lane
+            if (args.adapt_pool == 4) {
+                f(integrate_kernel<false, true, false, false, false, 4>, 23);
+                return;
+            }
+            if (args.adapt_pool == 2) {
+                f(integrate_kernel<false, true, false, false, false, 2>, 22);
+                return;
             }
         }
         if (args.may_leave_envelope) f(integrate_kernel<S, B, T, true>, ((S * 2 + B) * 2 + T) * 2 + 1);
@@ -2489,6 +2505,17 @@ void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
             tile_px = args.adapt_pool;
         }
     }
+    if (rays == 1 && big && !sky && !stats && args.error >= 0.0f && !args.may_leave_envelope && args.pass_begin >= 0 &&
+        args.pass_begin + args.pass_count <= kMaxBatchPass && force != 1) {
+        // the box-tree kernel (one ray slot per lane, six waves per SIMD) with adaptive sampling on: batches of 64 over 16 x 8 tiles,
+        // over 32 x 8 tiles where the frame has one and a half rounds of those
+        const uint32_t min_tiles = (force == 2 || force == 3) ? 0u : static_cast<uint32_t>(cu_count) * 4u * static_cast<uint32_t>(PT_WAVES_PER_SIMD) * 3u / 2u;
+        const uint32_t pool2_tiles = static_cast<uint32_t>((args.width + kTileW * 2 - 1) / (kTileW * 2)) * rows;
+        const uint32_t pool4_tiles = static_cast<uint32_t>((args.width + kTileW * 4 - 1) / (kTileW * 4)) * rows;
+        if (force != 2 && pool4_tiles >= min_tiles) args.adapt_pool = 4;
+        else if (pool2_tiles >= min_tiles) args.adapt_pool = 2;
+        if (args.adapt_pool) tile_px = args.adapt_pool;
+    }
     args.blocks_x = (args.width + kTileW * tile_px - 1) / (kTileW * tile_px);
     args.n_tiles = static_cast<uint32_t>(args.blocks_x) * rows;
 }
@@ -2497,7 +2524,7 @@ void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
 // calculation (registers, LDS, launch bounds): the scheduler's count of wave slots.  Asked once per instantiation and device.
 hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves) {
     constexpr int kDevices = 16;
-    static std::atomic<int> cache[kDevices][22];   // 0 = not asked yet
+    static std::atomic<int> cache[kDevices][24];   // 0 = not asked yet
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -193,6 +193,26 @@ def test_replicated_scene_bit_exact(tmp_path, instances, W, H, spp):
     assert st["exact_tests"] < 0.01 * st["segments"] * n
 
 
+@pytest.mark.parametrize("instances,W,H,spp,kw", [(8, 48, 32, 100, {"error": 0.05}), (64, 40, 16, 40, {"error": 0.2, "seed": 3})], ids=["x8", "x64"])
+def test_box_tree_batches_of_adaptive_sampling(tmp_path, hooks_lib, instances, W, H, spp, kw):
+    """Adaptive sampling on a scene under the box tree: the statistics-free kernel runs batches of 64 of its tile's 128 / 256 pixels,
+    each at its own next pass (pt_kernels.hip "Batches"; one ray slot per lane here) -- the oracle's bits for every tile width (1 = the
+    plain 8 x 8 kernel that sits passes out)."""
+    d, name, n = _replicated(tmp_path, instances)
+    o = O.Scene.load(d, name)
+    rs, rs2, rc, rst = O.render(o, W, H, spp, 8, rng=O.RNG_COUNTER, trig=O.TRIG_PORTABLE, **kw)
+    assert rst["samples_traced"] < 0.95 * W * H * spp and rc.sum() > 0     # the adaptive skip bites (pixels without a contribution never sit out)
+    for width_mode in (3.0, 2.0, 1.0):
+        hooks_lib.pt_test_set_mutation(b"tile_width", width_mode)
+        try:
+            h = pt.Scene.load_obj(d, name, device=0, library=hooks_lib)
+            assert len(h.cull_layout()["bvh"]) > 0
+            s, s2, c, _ = h.render_host(W, H, spp, 8, want_stats=False, **kw)
+        finally:
+            hooks_lib.pt_test_set_mutation(b"reset", 0.0)
+        assert np.array_equal(c, rc) and _same(s, rs) and _same(s2, rs2), width_mode
+
+
 def test_many_candidates_per_ray(tmp_path):
     # a deep stack of large coplanar-ish sheets in front of the camera: every ray has dozens of candidate triangles,
     # so the (ray, triangle) queue needs several batches and the slots several flushes

@@ -97,6 +97,24 @@ def test_batches_of_adaptive_sampling(models_dir, vlib, error, spp, tile_width):
     assert moved > 30 and narrow["partial_commit_rounds"] == 0, moved
 
 
+@pytest.mark.parametrize("tile_width", [2, 3], ids=["16x8", "32x8"])
+@pytest.mark.parametrize("instances,spp", [(9, 96), (64, 48)], ids=["x9", "x64"])
+def test_box_tree_batches_of_adaptive_sampling(tmp_path, vlib, instances, spp, tile_width):
+    """The same batches in the box-tree kernel (one ray slot per lane: 64 of the tile's 128 / 256 pixels per batch), with its
+    can-reach filter on last segments: every segment against the all-triangles loop, and pixels really did move between lanes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_replicated_scene as M
+    d = str(tmp_path) + "/"
+    M.generate(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models"), d, "r.obj", instances)
+    vlib.pt_test_set_mutation(b"tile_width", float(tile_width))
+    try:
+        st = _check(vlib, d, "r.obj", 320, 176, spp, 8, error=0.001, seed=5)
+    finally:
+        vlib.pt_test_set_mutation(b"reset", 0.0)
+    assert st["verify_mismatches"] == 0 and st["partial_commit_rounds"] > 30, st
+
+
 def test_every_segment_of_the_x64_replica_on_the_shipped_instantiation(tmp_path, vlib):
     """BASELINE configs[4] geometry at 1080p x 4 spp: the big-scene kernel with its can-reach filter on last segments."""
     d, name = _replica(tmp_path, 64)

@@ -42,6 +42,8 @@ HOT = {
     "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb0ELi4EEEvNS_10RenderArgsE": ("the same over 32 x 8 tiles", 5, 7680),
     "_ZN2pt16integrate_kernelILb0ELb0ELb0ELb0ELb1ELi0EEEvNS_10RenderArgsE": ("small scenes, one pixel per lane (small launches)", 6, 6400),
     "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE": ("big scenes (box tree)", 6, 6400),
+    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELi2EEEvNS_10RenderArgsE": ("the same with adaptive sampling on (batches over 16 x 8 tiles)", 6, 6400),
+    "_ZN2pt16integrate_kernelILb0ELb1ELb0ELb0ELb0ELi4EEEvNS_10RenderArgsE": ("the same over 32 x 8 tiles", 6, 6400),
     "_ZN2pt16integrate_kernelILb1ELb0ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE": ("small scenes under a skybox (path regeneration)", 5, 7680),
     "_ZN2pt16integrate_kernelILb1ELb1ELb0ELb0ELb0ELi0EEEvNS_10RenderArgsE": ("big scenes under a skybox", 5, 7680),
 }
