@@ -601,6 +601,12 @@ def main():
                       if pmc_big and pmc_big.get("TCP_TOTAL_CACHE_ACCESSES_sum") and pmc_big.get("GRBM_GUI_ACTIVE") else None}
                 r["roofline"] = rf
             rep[f"x{inst}"] = r
+            if inst == 64:   # the same scene with the reference's default -ERR 0.001: the box-tree kernel's batches of adaptive sampling
+                ra, sta = leg(big_scene, BASE_W, BASE_H, SPP, 2, f"the x {inst} scene, {BASE_W}x{BASE_H} x {SPP} spp, -MRR {MRR}, -ERR 0.001 (reference default)", error=0.001)
+                ra["samples_traced"] = int(sta["samples_traced"])
+                ra["value_traced"] = ra["value"] * ra["samples_traced"] / (BASE_W * BASE_H * SPP)
+                ra["what"] = "value = nominal W*H*spp per second (the reference's own accounting)"
+                rep[f"x{inst}_adaptive_default"] = ra
             big_scene.close()
         legs["configs4_replica"] = rep
 

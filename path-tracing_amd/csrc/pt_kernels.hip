@@ -1463,6 +1463,9 @@ __device__ __forceinline__ void closest_hit(const RenderArgs &a, Lds &lds, const
 #define PT_RAYS_PER_LANE 2   // pixels (rays) per lane of the small-scene, statistics-free, skybox-free kernel; 1 = one 8 x 8 tile per wave
 #endif
 constexpr int kMaxBatchPass = 32766;   // adaptive instantiations: a pixel's next pass (at most one past the launch's last) << 1 | a flag in 16 bits
+#ifndef PT_ADAPT4_DYN
+#define PT_ADAPT4_DYN 0   // 32 x 8 adaptive kernel: 1 = batches of at most 64 switch the second ray slots off (scalar branches around every per-ray piece)
+#endif
 #ifndef PT_ADAPT_TWO_AT
 #define PT_ADAPT_TWO_AT 100   // adaptive kernels: pixels with a pass to run from which a batch takes up to 128, two per lane (80 ... 112 within 1 %, adapt3)
 #endif
@@ -1498,6 +1501,10 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
     // nothing and would cost the last-segment filter, which needs the wave's rays to reach their last segment together.
     constexpr bool REGEN = SKY;
     static_assert(!REGEN || !ADAPT, "the compacting instantiation keeps the pass loop");
+    // kDynSlots: batches of at most 64 pixels run with the second ray slots switched off (scalar branches around every per-ray piece of
+    // the search and of shading).  The 16 x 8 kernel has them -- a third of its batches are such -- the 32 x 8 kernel does not: one batch
+    // in eleven is, and the branches cost every batch 3-4 % (1080p 56.0 -> 54.1 ms, 3840 x 2160 215.5 -> 207.2, r04_ab_logs.txt adapt5).
+    constexpr bool kDynSlots = ADAPT != 0 && R == 2 && (ADAPT != 4 || PT_ADAPT4_DYN);
     constexpr int kOwn = ADAPT ? ADAPT : R;   // pixels of the tile per lane: pixel j of the tile = column (j % 8) + 8 (j / 64), row (j % 64) / 8
     constexpr int kTW = kTileW * kOwn;
     __shared__ WaveLds<std::conditional_t<BIG, std::conditional_t<ADAPT != 0, BigQueuesAdapt<ADAPT>, BigQueues>, std::conditional_t<(R > 1), SmallQueues2, SmallQueues>>, R, ADAPT> lds;   // one wave per workgroup: all wave-private
@@ -1766,7 +1773,8 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
                 behind = min(behind, pend[kb] ? np[kb] : ~0u);
             }
             if (n_pend == 0) break;
-            const uint32_t quota = (R == 2 && n_pend >= static_cast<uint32_t>(PT_ADAPT_TWO_AT)) ? 128u : 64u;   // (the box-tree kernel has one ray slot per lane)
+            // (the box-tree kernel has one ray slot per lane; without kDynSlots a batch costs the same however few it holds)
+            const uint32_t quota = (R == 2 && (!kDynSlots || n_pend >= static_cast<uint32_t>(PT_ADAPT_TWO_AT))) ? 128u : 64u;
             if (n_pend > quota) {
                 const uint32_t m = wave_min(behind);
                 uint32_t at_a = 0, at_b = 0, rank_a[kOwn], rank_b[kOwn];
@@ -1812,7 +1820,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
             for (int kb = 0; kb < kOwn; ++kb)   // the owners: the chosen pixels' next pass
                 lds.low.v[le + 64u * kb] = static_cast<uint16_t>(((np[kb] + (sel[kb] ? 1u : 0u)) << 1) | (word[kb] & 1u));
         }
-        const bool k1_on = two;   // (PT_SLOT_ON)
+        const bool k1_on = kDynSlots ? two : true;   // (PT_SLOT_ON)
 
         // Primary ray, main.cpp:126-129 + Ray ctor ray.h:21-25 (double arithmetic, then narrowed).
         auto primary_dir = [&](int k, int pass_k, float &out_dx, float &out_dy, float &out_dz) {
@@ -2000,7 +2008,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
             }
             for (;;) {
                 if (BIG && !any_of(searched)) break;
-                closest_hit<ENV, kLastSegmentFilter, (ADAPT != 0)>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase, two);
+                closest_hit<ENV, kLastSegmentFilter, kDynSlots>(a, lds, q, searched, inside, lane, eps, best, hit, hit_rec, wst, emis_phase, two);
                 if (!emis_phase) break;
                 emis_phase = false;
 #pragma unroll

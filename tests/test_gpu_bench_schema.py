@@ -76,6 +76,8 @@ def test_bench_emits_one_valid_json_line():
     assert 0 < rb["useful_fraction"] < rb["frac_active_lanes"] < rb["frac"] <= 1.0
     assert 0.3 < rb["l1_hit_rate"] < 1.0 and rb["issue"]["instructions_per_wave_segment"] > 500
     assert rep["x64"]["node_rounds_per_wave_segment"] > 1
+    ra = rep["x64_adaptive_default"]      # the reference's default -ERR 0.001 on the same scene: fewer samples traced, more nominal samples per second
+    assert ra["samples_traced"] < 0.9 * 1920 * 1080 * 256 and ra["value"] > rep["x64"]["value"]
     # BASELINE configs[2] (1024 spp) with the HBM bytes of that launch, and the open scene under a sky (path regeneration)
     c2 = j["configs2_1024spp"]
     assert "1024 spp" in c2["workload"] and c2["value"] > 100.0 and c2["steps"] == 3
