@@ -2498,16 +2498,19 @@ void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
     int tile_px = rays;   // tile width in 8-pixel column blocks
     if (rays > 1) {
         const uint32_t wide_tiles = static_cast<uint32_t>((args.width + kTileW * rays - 1) / (kTileW * rays)) * rows;
-        // one and a half rounds of its waves (measured, profiles/r03_ab_logs.txt ab53: 7 200 tiles -19 %, 8 160 tiles +3 %, 16 200 +6.6 %)
-        uint32_t min_tiles = static_cast<uint32_t>(cu_count) * 4u * static_cast<uint32_t>(PT_WAVES_PER_SIMD - 1) * 3u / 2u;
-        if (force == 1) min_tiles = 0xFFFFFFFFu;   // (test builds: always 8 x 8 / always 16 x 8 / always 32 x 8 with adaptive sampling on)
-        if (force == 2 || force == 3) min_tiles = 0;
-        if (wide_tiles < min_tiles) {
+        // adaptive sampling on: the instantiations that run batches (not built with the rare envelope test: one more spilled
+        // register there)
+        const bool batches = !big && args.error >= 0.0f && !args.may_leave_envelope && args.pass_begin >= 0 && args.pass_begin + args.pass_count <= kMaxBatchPass;
+        // one and a half rounds of its waves (measured, profiles/r03_ab_logs.txt ab53: 7 200 tiles -19 %, 8 160 tiles +3 %, 16 200 +6.6 %);
+        // the batch kernel beats the 8 x 8 kernel's sitting out from 1.2 rounds on (1280 x 720: 29.0 against 31.7 ms, r04_ab_logs.txt adapt6)
+        const uint32_t slots = static_cast<uint32_t>(cu_count) * 4u * static_cast<uint32_t>(PT_WAVES_PER_SIMD - 1);
+        uint32_t min_tiles = slots * 3u / 2u, min_wide = batches ? slots * 6u / 5u : min_tiles;
+        if (force == 1) min_tiles = min_wide = 0xFFFFFFFFu;   // (test builds: always 8 x 8 / always 16 x 8 / always 32 x 8 with adaptive sampling on)
+        if (force == 2 || force == 3) min_tiles = min_wide = 0;
+        if (wide_tiles < min_wide) {
             rays = tile_px = 1;
             args.narrow = 1;
-        } else if (!big && args.error >= 0.0f && !args.may_leave_envelope && args.pass_begin >= 0 && args.pass_begin + args.pass_count <= kMaxBatchPass) {
-            // adaptive sampling on: the instantiations that run batches (not built with the rare envelope test: one more spilled
-            // register there) -- over 32 x 8 tiles if there are enough of those as well, else over 16 x 8 tiles
+        } else if (batches) {   // over 32 x 8 tiles if there are enough of those as well, else over 16 x 8 tiles
             const uint32_t pool4_tiles = static_cast<uint32_t>((args.width + kTileW * 4 - 1) / (kTileW * 4)) * rows;
             args.adapt_pool = (force != 2 && pool4_tiles >= min_tiles) ? 4 : 2;
             tile_px = args.adapt_pool;
