@@ -769,25 +769,30 @@ def main():
             # end to end: the stand-alone front end from process start to the BMP on disk -- exec + dynamic
             # linking, OBJ/MTL parse, HIP start-up, table upload, hierarchy build, render, read-back, resolve (powf), BMP write,
             # exit.  A child process; -T0_NS lets it report the time before main().
-            with tempfile.TemporaryDirectory() as td:
-                cmd = [EXE, "--W", str(W), "--H", str(H), "-RPP", str(args.spp), "-MRR", str(MRR), "-ERR", "-1", "-UPDATE", "0",
-                       "-QUIET", "1", "-SEED", "42", "-MODEL_PATH", MODELS, "-OUT", os.path.join(td, "frame.bmp"), "-TIMING", "1",
-                       "-FASTEXIT", "1", "-T0_NS", str(time.time_ns())]
-                te = time.perf_counter()
-                r = subprocess.run(cmd, cwd=td, capture_output=True, text=True)
-                te = time.perf_counter() - te
-                ok = r.returncode == 0 and os.path.getsize(os.path.join(td, "frame.bmp")) == 54 + W * H * 3
-                phases = None
-                for line in r.stderr.splitlines():
-                    if line.startswith("{") and "hip_startup_s" in line:
-                        phases = json.loads(line)
+            runs = []
+            for _ in range(2):   # twice: the runtime's start-up beside a parent that holds the device varies from 0.05 to 0.25 s; both are reported
+                with tempfile.TemporaryDirectory() as td:
+                    cmd = [EXE, "--W", str(W), "--H", str(H), "-RPP", str(args.spp), "-MRR", str(MRR), "-ERR", "-1", "-UPDATE", "0",
+                           "-QUIET", "1", "-SEED", "42", "-MODEL_PATH", MODELS, "-OUT", os.path.join(td, "frame.bmp"), "-TIMING", "1",
+                           "-FASTEXIT", "1", "-T0_NS", str(time.time_ns())]
+                    te = time.perf_counter()
+                    r = subprocess.run(cmd, cwd=td, capture_output=True, text=True)
+                    te = time.perf_counter() - te
+                    ok = r.returncode == 0 and os.path.getsize(os.path.join(td, "frame.bmp")) == 54 + W * H * 3
+                    phases = None
+                    for line in r.stderr.splitlines():
+                        if line.startswith("{") and "hip_startup_s" in line:
+                            phases = json.loads(line)
+                runs.append((te if ok else float("inf"), te, ok, phases))
+            _, te, ok, phases = min(runs, key=lambda x: x[0])
             unexplained = None
             if phases:
                 unexplained = te - phases["pre_main_s"] - phases["main_s"]
             out["end_to_end"] = {"value": samples_per_step / te / 1e6 if ok else None, "unit": "Msamples/s", "seconds": te,
+                                 "seconds_of_both_runs": [x[1] for x in runs],
                                  "phases": phases, "exit_and_wait_s": unexplained,
-                                 "what": "pt_render (C++ front end) as a child process: process start -> BMP on disk -> exit; "
-                                         "seconds = pre_main_s + main_s + exit_and_wait_s"}
+                                 "what": "pt_render (C++ front end) as a child process: process start -> BMP on disk -> exit, the faster of two "
+                                         "runs; seconds = pre_main_s + main_s + exit_and_wait_s"}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], out["accuracy"] = cpu_baseline(MODELS, args.cpu_seconds, pt, scene)
             out["accuracy"]["vs_reference_stream"] = reference_stream_accuracy(MODELS, pt, scene)

@@ -33,6 +33,8 @@ d = tempfile.mkdtemp() + "/"
 for n, spp in ((64, 32), (195, 16)):
     M.generate(os.path.join(ROOT, "models"), d, f"x{n}.obj", n)
     jobs.append((f"configs[4] x{n} replica 1920x1080x{spp}spp", d, f"x{n}.obj", 1920, 1080, spp, -1.0))
+    if shipped and n == 64:   # the box-tree kernel's batches of adaptive sampling (16 x 8 tiles at this size)
+        jobs.append((f"x{n} replica 1920x1080x48spp -ERR 0.001", d, f"x{n}.obj", 1920, 1080, 48, 0.001))
 # an open scene under a sky: the skybox instantiations (path regeneration; the torus x9 likewise for the box tree)
 import make_open_scene as MO
 MO.generate(os.path.join(ROOT, "models"), d)
