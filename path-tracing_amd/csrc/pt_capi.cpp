@@ -1106,8 +1106,11 @@ int pt_post_filter_host(int device, int32_t width, int32_t height, float *rgb, i
 
 #ifdef PT_TEST_HOOKS
 // Test build only (libpt_testhooks.so).  family: "sphere_r2", "m0", "k12", "a_max", "quad_slack" (scale on that family of
-// conservative margins; 1 = as shipped), "no_absorb" (0/1), "items_per_slot" (scheduler), "reset".  Affects scenes whose
-// cull tables are built afterwards.
+// conservative margins; 1 = as shipped), "no_absorb" (0/1), "reset".  Affects scenes whose cull tables are built afterwards.
+// Scheduler / instantiation choices of launches enqueued afterwards: "items_per_slot" (n > 0: equal pass chunks, about n work items
+// per wave slot; < 0: the 3/4 - of - the - rest chunks always; 0: the library's rule), "chunk_min" (the smallest last chunk of that
+// scheme), "tile_width" (1: 8 x 8 tiles always; 2: 16 x 8 where the instantiation has them, batches over 16 x 8 tiles for adaptive
+// launches; 3: the same with 32 x 8 batch tiles; 0: by tile count), "regen_min_dead" (path regeneration threshold).
 // Test builds only: both forms of the box tree's child test (pt_kernels.hip: box_children_kept / box_children_kept_h) on n
 // caller-supplied items -- nodes: n x 64 bytes (BvhNode), rays: n x 6 floats (origin, unit direction), t_best: n floats --
 // out: 2 n masks (float form, half-precision form).  Host pointers; device 0.
