@@ -1895,9 +1895,6 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
                 // Regeneration: a slot whose path is over takes its pixel's next pass -- after the adaptive skip of
                 // main.cpp:118-125, which sits out passes > 10 that are not multiples of 4 while the variance is low: the next
                 // one that runs is then the next multiple of 4.
-                // Regeneration: a slot whose path is over takes its pixel's next pass -- after the adaptive skip of
-                // main.cpp:118-125, which sits out passes > 10 that are not multiples of 4 while the variance is low: the next
-                // one that runs is then the next multiple of 4.
                 // The primary-ray code (Philox, two double-precision divisions, a normalisation) costs about a third of a segment
                 // however few lanes run it, so it runs only once a.regen_min_dead slots of the wave wait for a path, or when no
                 // ray of the wave is alive (a.regen_min_dead = 64: the wave's passes stay in step, as without regeneration).  The
