@@ -2541,6 +2541,19 @@ hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves) {
         int n = dev < kDevices ? cache[dev][id].load(std::memory_order_relaxed) : 0;
         if (n == 0) {
             result = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0);
+            if (result == hipSuccess && n > 0) {
+                // The runtime's calculator divides the CU's LDS by the kernel's bytes; the hardware hands LDS out in granules of 1 280
+                // bytes (tools/lds_granule_probe.hip, profiles/r04_lds_granule.txt: 7 888 B -> 18 workgroups run, the runtime says 20).
+                hipFuncAttributes fa;
+                hipDeviceProp_t prop;
+                if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel)) == hipSuccess && fa.sharedSizeBytes > 0 &&
+                    hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor > 0) {
+                    constexpr size_t kLdsGranule = 1280;
+                    const size_t per_wave = (fa.sharedSizeBytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
+                    const size_t by_lds = std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlock) / per_wave;
+                    if (by_lds >= 1 && by_lds < static_cast<size_t>(n)) n = static_cast<int>(by_lds);
+                }
+            }
             if (result != hipSuccess || n <= 0) n = 0;
             else if (dev < kDevices) cache[dev][id].store(n, std::memory_order_relaxed);
         }
