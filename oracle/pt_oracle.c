@@ -949,6 +949,44 @@ void orc_probe_sincos(const float *a, int n, int policy, float *s, float *c) {
         else portable_sincosf(a[i], &s[i], &c[i]);
     }
 }
+/* One Scene::TraceRay call per caller-supplied ray with caller-supplied random words (the counter policy's conversion to (0, 1)
+ * floats; trig_policy as in orc_params): rays in and out (o, d [n][3], color [n][3], depth [n]), what the call added to the
+ * pixel's accumulators (contrib [n][3]) and whether it added anything (contributed [n]).  For tests/test_double_entry.py. */
+void orc_probe_segments(const orc_scene *sc, int n, float eps, int mrr, int trig_policy, float *o, float *d, float *color, int *depth,
+                        const uint32_t *rnd, float *contrib, int *contributed) {
+    for (int i = 0; i < n; ++i) {
+        orc_params pr;
+        memset(&pr, 0, sizeof pr);
+        pr.eps = eps; pr.max_ray_reflections = mrr; pr.rng_policy = ORC_RNG_COUNTER; pr.trig_policy = trig_policy;
+        orc_stats st;
+        memset(&st, 0, sizeof st);
+        float sum[3] = {0, 0, 0}, sum2[3] = {0, 0, 0};
+        int count = 0;
+        orc_ctx cx;
+        memset(&cx, 0, sizeof cx);
+        cx.sc = sc; cx.pr = &pr; cx.sum = sum; cx.sum2 = sum2; cx.count = &count; cx.st = &st;
+        for (int k = 0; k < 3; ++k) cx.rnd[k] = rnd[3 * (size_t)i + k];
+        orc_ray r;
+        for (int k = 0; k < 3; ++k) { r.o[k] = o[3 * (size_t)i + k]; r.d[k] = d[3 * (size_t)i + k]; r.color[k] = color[3 * (size_t)i + k]; }
+        r.depth = depth[i];
+        trace_segment(&cx, &r);
+        for (int k = 0; k < 3; ++k) { o[3 * (size_t)i + k] = r.o[k]; d[3 * (size_t)i + k] = r.d[k]; color[3 * (size_t)i + k] = r.color[k]; contrib[3 * (size_t)i + k] = sum[k]; }
+        depth[i] = r.depth;
+        contributed[i] = count;
+    }
+}
+/* The primary ray's direction for pixel (x, y) and the two jitter draws (main.cpp:126-129, ray.h:21-25), and the adaptive-sampling
+ * answer for a pixel's accumulators before pass `pass` (main.cpp:118-125; 1 = the pixel sits the pass out).  For tests/test_double_entry.py. */
+void orc_probe_primary(int n, const int *x, const int *y, const double *jx, const double *jy, int W, int H, float *d) {
+    for (int i = 0; i < n; ++i) {
+        orc_ray r;
+        primary_ray(&r, x[i], y[i], jx[i], jy[i], W, H);
+        d[3 * (size_t)i] = r.d[0]; d[3 * (size_t)i + 1] = r.d[1]; d[3 * (size_t)i + 2] = r.d[2];
+    }
+}
+void orc_probe_adaptive_skip(int n, const int *pass, const float *c, const float *c2, const int *count, float error, int *skip) {
+    for (int i = 0; i < n; ++i) skip[i] = adaptive_skip(pass[i], c + 3 * (size_t)i, c2 + 3 * (size_t)i, count[i], error);
+}
 /* Per-stage test of one triangle (T2-style vectors). */
 int orc_probe_intersect(const orc_scene *s, int tri, const float *o, const float *d, float eps, float best_in, float *best_out) {
     float dist = best_in;

@@ -75,6 +75,12 @@ def lib():
         L.orc_probe_acos_atan2.argtypes = [fp, fp, fp, C.c_int, C.c_int, fp, fp]
         L.orc_probe_sincos.argtypes = [fp, C.c_int, C.c_int, fp, fp]
         L.orc_probe_intersect.argtypes = [vp, C.c_int, fp, fp, C.c_float, C.c_float, fp]
+        L.orc_probe_primary.restype = None
+        L.orc_probe_primary.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, fp]
+        L.orc_probe_adaptive_skip.restype = None
+        L.orc_probe_adaptive_skip.argtypes = [C.c_int, C.POINTER(C.c_int), fp, fp, C.POINTER(C.c_int), C.c_float, C.POINTER(C.c_int)]
+        L.orc_probe_segments.restype = None
+        L.orc_probe_segments.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.c_int, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_uint32), fp, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -145,6 +151,20 @@ class Scene:
             raise RuntimeError("the scene has no skybox")
         return out
 
+    def segments(self, origins, directions, colors, depths, words, eps=1e-4, mrr=8, trig=TRIG_LIBM):
+        """One Scene::TraceRay call per ray (begin, unit direction, throughput, depth) with the three random words given: the rays
+        afterwards, what was added to the accumulators, and whether anything was."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3).copy()
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3).copy()
+        c = np.ascontiguousarray(colors, np.float32).reshape(-1, 3).copy()
+        dep = np.ascontiguousarray(depths, np.int32).copy()
+        w = np.ascontiguousarray(words, np.uint32).reshape(-1, 3)
+        contrib = np.zeros_like(o)
+        did = np.zeros(len(o), np.int32)
+        lib().orc_probe_segments(self.h, len(o), eps, mrr, trig, _fp(o), _fp(d), _fp(c), _ip(dep), w.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                 _fp(contrib), _ip(did))
+        return o, d, c, dep, contrib, did.astype(bool)
+
     def closest_hits(self, origins, directions, eps=1e-4, threads=0):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
@@ -178,6 +198,23 @@ def render(scene, width, height, spp, mrr, *, eps=1e-4, error=-1.0, seed=42, rng
     stats = {"samples_traced": st.samples_traced, "segments": st.segments, "contributing": st.contributing,
              "stage_exit": list(st.stage_exit), "misses": st.misses}
     return s, s2, c, stats
+
+
+def primary_directions(x, y, jx, jy, width, height):
+    x, y = np.ascontiguousarray(x, np.int32), np.ascontiguousarray(y, np.int32)
+    jx, jy = np.ascontiguousarray(jx, np.float64), np.ascontiguousarray(jy, np.float64)
+    d = np.zeros((len(x), 3), np.float32)
+    dp = C.POINTER(C.c_double)
+    lib().orc_probe_primary(len(x), _ip(x), _ip(y), jx.ctypes.data_as(dp), jy.ctypes.data_as(dp), width, height, _fp(d))
+    return d
+
+
+def adaptive_skip(passes, s, s2, c, error):
+    passes, c = np.ascontiguousarray(passes, np.int32), np.ascontiguousarray(c, np.int32)
+    s, s2 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(s2, np.float32)
+    out = np.zeros(len(c), np.int32)
+    lib().orc_probe_adaptive_skip(len(c), _ip(passes), _fp(s), _fp(s2), _ip(c), error, _ip(out))
+    return out.astype(bool)
 
 
 def resolve(width, height, s, s2, c, gamma=np.float32(1 / np.float32(2.2))):
