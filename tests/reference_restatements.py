@@ -334,8 +334,7 @@ def trace_segment(planes, verts, squares, tri_mat, mats10, o, d, color, depth, x
     indexes chance_ / functions_ out of range (material.h:44-48 when the chances do not use the sample up)."""
     o, d, color = np.asarray(o, F), np.asarray(d, F), np.asarray(color, F)
     eps = F(eps)
-    idx, dist = trace_rays(planes, verts, squares, o[None], d[None], eps)
-    i, t = int(idx[0]), dist[0]
+    i, t = trace_one(planes, verts, squares, o, d, eps)                 # (scene.cpp:114-120; the triangle-by-triangle form is trace_rays)
     if i < 0:                                                            # scene.cpp:125, 155
         return o, d, color, mrr, None, True
     drop = (o + (d * t).astype(F)).astype(F)                             # :122
@@ -438,3 +437,105 @@ def resolve(color, color2, samples, gamma):
         for k in range(3):
             rgb[yy, xx, k] = F(F(_libm.powf(float(m[yy, xx, k]), g)) * F(255))
     return rgb, np.array([max_d, min_d, avg], F)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# main() itself, one thread: the pass loop (main.cpp:110-140) with the reference's own two random streams.  Both are
+# std::default_random_engine = minstd_rand0 seeded with Config::getSeed() (main.cpp:91, material.h:17): x <- 16807 x mod (2^31 - 1),
+# first state = the seed.  What the distributions do with the engine is libstdc++'s published <random> (bits/random.tcc,
+# generate_canonical; this image's GCC 11 headers): with r = max - min + 1 = 2147483646 (a long double), log2r = 30,
+#     float  (24 bits, 1 draw):   float(u - 1) / float(r)                                   [float(r) = 2147483648]
+#     double (53 bits, 2 draws):  (double(u1 - 1) + double(u2 - 1) * 2147483646) / double(r * r)
+# clamped below 1, then a + canonical * (b - a).  The two jitter draws of a pixel sit in one constructor call
+# (main.cpp:126-128); g++ evaluates its arguments right to left, so y's is drawn first (what the recorded frames of SURVEY 8(c) fix).
+# ---------------------------------------------------------------------------------------------------------------------
+class MinStd0:
+    def __init__(self, seed):
+        s = int(seed) % 2147483647
+        self.x = s if s != 0 else 1
+
+    def __call__(self):
+        self.x = (self.x * 16807) % 2147483647
+        return self.x
+
+
+def canonical_float(eng):
+    ret = F(F(eng() - 1) * F(1)) / F(2147483646.0)          # __sum / __tmp, __tmp = float(1 * r)
+    return np.nextafter(F(1), F(0)) if ret >= F(1) else F(ret)
+
+
+def canonical_double(eng):
+    s = np.float64(eng() - 1) * np.float64(1)
+    s = s + np.float64(eng() - 1) * np.float64(2147483646.0)
+    ret = s / np.float64(float(2147483646 * 2147483646))
+    return np.nextafter(np.float64(1), np.float64(0)) if ret >= 1 else ret
+
+
+def trace_one(planes, verts, squares, o, d, eps):
+    """trace_rays for one ray, all triangles at once: the loop's running `distance` makes the answer the smallest accepted distance,
+    the first such triangle on a tie (triangles.h:51: `>=` rejects an equal later one)."""
+    o, d, eps = np.asarray(o, F), np.asarray(d, F), F(eps)
+    with np.errstate(all="ignore"):
+        p = planes
+        sd = (((d[0] * p[:, 0]).astype(F) + (d[1] * p[:, 1]).astype(F)).astype(F) + (d[2] * p[:, 2]).astype(F)).astype(F)
+        num = ((((o[0] * p[:, 0]).astype(F) + (o[1] * p[:, 1]).astype(F)).astype(F) + (o[2] * p[:, 2]).astype(F)).astype(F) + p[:, 3]).astype(F)
+        nd = ((-num).astype(F) / sd).astype(F)
+        drop = (o[None, :] + (d[None, :] * nd[:, None]).astype(F)).astype(F)
+        f0, f1, f2 = (drop - verts[:, 0]).astype(F), (drop - verts[:, 1]).astype(F), (drop - verts[:, 2]).astype(F)
+        s1, s2, s3 = _length(_cross(f0, f1)), _length(_cross(f0, f2)), _length(_cross(f2, f1))
+        lim = (squares + eps).astype(F)
+        ok = (~(nd < eps) & ~np.isnan(nd) & ~(s1 > lim) & ~((s1 + s2).astype(F) > lim) &
+              ~(np.abs((((squares - s1).astype(F) - s2).astype(F) - s3).astype(F)) > eps) & (nd < np.inf))
+    if not ok.any():
+        return -1, F(np.inf)
+    best = np.where(ok, nd, F(np.inf)).min()
+    return int(np.flatnonzero(ok & (nd == best))[0]), F(best)
+
+
+def render_sequential(planes, verts, squares, tri_mat, mats10, width, height, spp, mrr, eps, error, seed):
+    """main.cpp:91-140 on one thread: (color_map, color2_map, samples_count) as [H, W, 3], [H, W, 3], [H, W]."""
+    gen = MinStd0(seed)                                                  # main.cpp:91
+    mat_gen = MinStd0(seed)                                              # material.h:17
+    color = np.zeros((height, width, 3), F)
+    color2 = np.zeros((height, width, 3), F)
+    samples = np.zeros((height, width), np.int64)
+    for rays_count in range(spp):                                        # :110
+        rays = {}
+        for y in range(height):                                          # :116-117
+            for x in range(width):
+                if adaptive_skip(np.array([rays_count]), color[y, x][None], color2[y, x][None], samples[y, x][None], error)[0]:
+                    continue                                             # :118-125 (the ray of the previous pass stays: it is invalid)
+                jy = canonical_double(gen) * np.float64(1.0) + np.float64(-0.5)      # :128 is evaluated before :127 (g++)
+                jx = canonical_double(gen) * np.float64(1.0) + np.float64(-0.5)
+                rays[(x, y)] = (np.array([0, 0, -20], F), primary_direction([x], [y], [jx], [jy], width, height)[0], np.ones(3, F), 0)
+        for y in range(height):                                          # :132-140
+            for x in range(width):
+                if (x, y) not in rays:
+                    continue
+                o, d, c, depth = rays[(x, y)]
+                while depth < mrr and (c != 0).any():                    # ray.h:52-54
+                    i, _ = trace_one(planes, verts, squares, o, d, eps)
+                    lobes = lobes_of(mats10[tri_mat[i]]) if i >= 0 else []
+                    xi = [F(0)] * 3                                      # Random() is drawn where the code reaches it, in order
+                    if len(lobes) > 1:
+                        xi[0] = canonical_float(mat_gen)
+                    # which lobe?  (the same walk as trace_segment's, to know whether the diffuse lobe's two draws happen)
+                    kind = None
+                    if len(lobes) == 1:
+                        kind = lobes[0][0]
+                    elif len(lobes) > 1:
+                        sample, k = xi[0], -1
+                        while sample > 0 and k + 1 < len(lobes):
+                            k += 1
+                            sample = F(sample - lobes[k][1])
+                        kind = lobes[max(k, 0)][0]
+                    if kind == 2:
+                        xi[1] = canonical_float(mat_gen)
+                        xi[2] = canonical_float(mat_gen)
+                    o, d, c, depth, contrib, defined = trace_segment(planes, verts, squares, tri_mat, mats10, o, d, c, depth, xi, eps, mrr)
+                    assert defined
+                    if contrib is not None:                              # material.h:73-76
+                        color[y, x] = (color[y, x] + contrib).astype(F)
+                        color2[y, x] = (color2[y, x] + (contrib * contrib).astype(F)).astype(F)
+                        samples[y, x] += 1
+    return color, color2, samples

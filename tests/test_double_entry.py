@@ -138,6 +138,9 @@ def test_trace_ray_two_restatements_agree(models_dir, seed, eps):
     both = idx >= 0
     assert np.array_equal(_bits(t[both]), _bits(ot[both]))
     assert both.mean() > (0.9 if eps >= 1e-4 else 0.3)      # (with eps = 1e-6 the area test's own rounding rejects every other hit)
+    for k in rng.integers(0, len(origins), 300):           # the all-triangles-at-once form the per-ray restatements below use
+        i1, t1 = N.trace_one(planes, verts, squares, origins[k], dirs[k], eps)
+        assert i1 == idx[k] and (i1 < 0 or _bits(t1) == _bits(t[k])), k
     # the ties and near-ties the `>=` of triangles.h:51 decides: several triangles accepted per ray on the torus's seams
     assert len(np.unique(idx[both])) > 150
 
@@ -192,7 +195,7 @@ def test_the_hit_branch_two_restatements_agree(tmp_path, models_dir, seed, mtl):
     assert np.array_equal(_bits(mats), _bits(o.materials()))
     if mtl:
         assert [tuple(k for k, _ in N.lobes_of(m)) for m in mats] == [(0,), (2,), (1,), (2,), (1, 2)]
-    n, eps, mrr = 700, 1e-4, 8
+    n, eps, mrr = 2500, 1e-4, 8
     origins = np.where(rng.random((n, 1)) < 0.3, np.array([[0, 0, -20]], np.float32), rng.uniform(-4, 4, (n, 3)).astype(np.float32)).astype(np.float32)
     tv = verts.reshape(-1, 3)
     aim = tv[rng.integers(0, len(tv), n)] + rng.normal(scale=0.3, size=(n, 3))
@@ -271,3 +274,22 @@ def test_resolve_two_restatements_agree():
         ok = (rgb < 256).all(2) & (cnt > 0)
         assert ok.sum() > 0.5 * H * W and np.array_equal(obgr[ok][:, ::-1], rgb[ok].astype(np.uint8))
         assert (obgr[cnt == 0] == 0).all()
+
+
+@pytest.mark.parametrize("W,H,spp,mrr,error,seed", [(24, 16, 4, 8, -1.0, 42), (12, 8, 24, 5, 0.05, 7), (9, 7, 16, 8, 0.001, 1234)],
+                         ids=["plain", "adaptive", "adaptive-default-threshold"])
+def test_the_whole_program_two_restatements_agree(models_dir, W, H, spp, mrr, error, seed):
+    """main.cpp:91-140 on one thread with the reference's own two minstd_rand0 streams (libstdc++'s generate_canonical written out
+    from its published source), every piece above composed -- camera jitter drawn y first, a path's draws taken where the code reaches
+    them, contributions added in path order, the adaptive skip looking at the sums so far -- against the oracle in the mode that
+    reproduces the reference's recorded frames (sequential streams, libm trig, one thread): the same accumulator bits."""
+    planes, verts, squares, tri_mat = N.load_obj_triangles(os.path.join(models_dir, "Tor.obj"))
+    mats = N.load_mtl(os.path.join(models_dir, "Tor.mtl"))
+    color, color2, samples = N.render_sequential(planes, verts, squares, tri_mat, mats, W, H, spp, mrr, 1e-4, error, seed)
+    o = O.Scene.load(models_dir, "Tor.obj")
+    s, s2, c, st = O.render(o, W, H, spp, mrr, eps=1e-4, error=error, seed=seed, rng=O.RNG_SEQUENTIAL, trig=O.TRIG_LIBM, threads=1)
+    assert samples.sum() > 0
+    assert np.array_equal(samples.ravel(), c)
+    assert np.array_equal(_bits(color.reshape(-1, 3)), _bits(s)) and np.array_equal(_bits(color2.reshape(-1, 3)), _bits(s2))
+    if error >= 0:
+        assert st["samples_traced"] < W * H * spp          # the skip happened
