@@ -6,6 +6,9 @@ Random123's published Philox4x32-10 known-answer vectors for the counter RNG.
 """
 import ctypes as C
 import hashlib
+import os
+import shutil
+import subprocess
 
 import numpy as np
 import pytest
@@ -32,6 +35,38 @@ def test_minstd_rand0_draws():
     assert np.array_equal(np.array(list(unit), np.float32), expect)
     assert jit[0] == 0.024587101791753829
     assert jit[1] == -0.23669445921572174
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+@pytest.mark.parametrize("seed", [42, 1, 7, 123456789, 2147483646, 2147483647, 0, 4000000000])
+def test_both_streams_against_this_platforms_libstdcxx(tmp_path, seed):
+    """The reference's two random streams are libstdc++'s default_random_engine under uniform_real_distribution<float>(0, 1) and
+    uniform_real_distribution<double>(-0.5f, 0.5f).  libstdc++ is here (it is g++'s): tests/native/libstdcxx_rng_main.cpp declares the
+    streams as the reference does and prints their draws; the oracle's restatement (minstd0 + generate_canonical as the oracle wrote
+    it) and the numpy one (tests/reference_restatements.py) must give the same bits -- 4 000 draws per stream and seed, seeds that hit
+    the engine's special cases (0 and 2^31 - 1 seed to state 1; values above 2^31 wrap)."""
+    import reference_restatements as N
+    exe = str(tmp_path / "rng")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "libstdcxx_rng_main.cpp")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, src], check=True)
+    n = 4000
+    out = subprocess.run([exe, str(seed), str(n)], capture_output=True, text=True, check=True).stdout.split()
+    raw = np.array([int(v) for k, v in zip(out[::2], out[1::2]) if k == "raw"], np.uint32)
+    unit = np.array([int(v, 16) for k, v in zip(out[::2], out[1::2]) if k == "unit"], np.uint32).view(np.float32)
+    jit = np.array([int(v, 16) for k, v in zip(out[::2], out[1::2]) if k == "jitter"], np.uint64).view(np.float64)
+    assert len(raw) == len(unit) == len(jit) == n
+    o_raw, o_unit, o_jit = (C.c_uint32 * n)(), (C.c_float * n)(), (C.c_double * n)()
+    O.lib().orc_probe_minstd(C.c_uint32(seed & 0xFFFFFFFF), n, o_raw, o_unit, o_jit)
+    assert np.array_equal(np.array(list(o_raw), np.uint32), raw)
+    assert np.array_equal(np.array(list(o_unit), np.float32).view(np.uint32), unit.view(np.uint32))
+    assert np.array_equal(np.array(list(o_jit), np.float64).view(np.uint64), jit.view(np.uint64))
+    e1, e2, e3 = N.MinStd0(seed), N.MinStd0(seed), N.MinStd0(seed)
+    k = 600
+    assert [e1() for _ in range(k)] == [int(v) for v in raw[:k]]
+    assert np.array_equal(np.array([N.canonical_float(e2) for _ in range(k)], np.float32).view(np.uint32), unit[:k].view(np.uint32))
+    mine = np.array([N.canonical_double(e3) * np.float64(1.0) + np.float64(-0.5) for _ in range(k)], np.float64)
+    assert np.array_equal(mine.view(np.uint64), jit[:k].view(np.uint64))
+    assert 0 < unit.min() and unit.max() < 1 and -0.5 <= jit.min() and jit.max() < 0.5
 
 
 def test_philox4x32_10_random123_kat():
