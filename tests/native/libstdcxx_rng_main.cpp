@@ -8,9 +8,30 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <random>
+#include <string>
 
 int main(int argc, char **argv) {
+    if (argc > 2 && std::strcmp(argv[1], "floats") == 0) {
+        // `parse` mode: every `v` / `vn` / `Kd` / `Ke` / `Ks` / `Ns` number of a model or material file as `ifstream >> float` reads it
+        // (scene.cpp:56-66, 73-82): the text-to-float conversion of the loader, done by the real library
+        std::ifstream file(argv[2]);
+        std::string input;
+        while (!file.eof()) {
+            file >> input;
+            if (file.eof()) break;
+            const int k = (input == "v" || input == "vn" || input == "Kd" || input == "Ke" || input == "Ks") ? 3 : input == "Ns" ? 1 : 0;
+            for (int i = 0; i < k; ++i) {
+                float v = 0;
+                file >> v;
+                uint32_t b;
+                std::memcpy(&b, &v, 4);
+                std::printf("%s %08x\n", input.c_str(), b);
+            }
+        }
+        return 0;
+    }
     const unsigned seed = argc > 1 ? static_cast<unsigned>(std::strtoul(argv[1], nullptr, 10)) : 42u;
     const int n = argc > 2 ? std::atoi(argv[2]) : 8;
     {

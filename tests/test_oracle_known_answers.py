@@ -69,6 +69,33 @@ def test_both_streams_against_this_platforms_libstdcxx(tmp_path, seed):
     assert 0 < unit.min() and unit.max() < 1 and -0.5 <= jit.min() and jit.max() < 0.5
 
 
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_text_to_float_against_this_platforms_libstdcxx(tmp_path, models_dir):
+    """The loader's numbers are `ifstream >> float` (scene.cpp:56-66, 73-82).  The same extraction by the real library, over every
+    vertex, normal and material number of Tor.obj / Tor.mtl, against the oracle's tables and the numpy restatement's strtof."""
+    import reference_restatements as N
+    exe = str(tmp_path / "rng")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "libstdcxx_rng_main.cpp")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, src], check=True)
+
+    def floats(path):
+        out = subprocess.run([exe, "floats", path], capture_output=True, text=True, check=True).stdout.split()
+        return [(k, int(v, 16)) for k, v in zip(out[::2], out[1::2])]
+
+    obj = floats(os.path.join(models_dir, "Tor.obj"))
+    v = np.array([b for k, b in obj if k == "v"], np.uint32).reshape(-1, 3)
+    planes, verts, squares, tri_mat = N.load_obj_triangles(os.path.join(models_dir, "Tor.obj"))
+    assert len(v) == 156 and set(map(tuple, verts.reshape(-1, 3).view(np.uint32))) <= set(map(tuple, v))
+    t14, _ = O.Scene.load(models_dir, "Tor.obj").triangles()
+    assert set(map(tuple, np.ascontiguousarray(t14[:, 4:13]).reshape(-1, 3).view(np.uint32))) <= set(map(tuple, v))
+    mtl = floats(os.path.join(models_dir, "Tor.mtl"))
+    mats = N.load_mtl(os.path.join(models_dir, "Tor.mtl"))
+    for key, cols in (("Kd", slice(0, 3)), ("Ke", slice(3, 6)), ("Ks", slice(6, 9)), ("Ns", slice(9, 10))):
+        want = np.array([b for k, b in mtl if k == key], np.uint32)
+        assert np.array_equal(mats[:, cols].ravel().view(np.uint32), want), key
+    assert np.array_equal(O.Scene.load(models_dir, "Tor.obj").materials().view(np.uint32), mats.view(np.uint32))
+
+
 def test_philox4x32_10_random123_kat():
     kat = [
         ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
