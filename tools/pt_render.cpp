@@ -103,6 +103,15 @@ int main(int argc, char **argv) {
     const long long start_time = now_ms();
     Options o;
     parse(argc, argv, o);
+    if (std::getenv("PT_RENDER_PRINT_CONFIG")) {   // tests/test_ref_parts.py: the parsed Config fields, as the reference's own parser is asked for them
+        const unsigned sd = o.seed < 0 ? static_cast<unsigned>(std::time(nullptr)) : static_cast<unsigned>(o.seed);
+        std::printf("height %d\nwidth %d\nrays_per_pixel %d\nmax_ray_reflections %d\nmedian %d\ngauss %d\neps %.9g\nerror %.9g\nupdate %d\n"
+                    "gamma_correction %.9g\nmodel_path %s\nmodel_name %s\nskybox %s\ntime_limit %d\nseed %u\n",
+                    o.height, o.width, o.rays_per_pixel, o.max_ray_reflections, o.median, o.gauss, static_cast<double>(o.eps),
+                    static_cast<double>(o.error), o.update, static_cast<double>(o.gamma_correction), o.model_path.c_str(),
+                    o.model_name.c_str(), o.skybox.c_str(), o.time_limit, sd);
+        return 0;
+    }
     if (o.width <= 0 || o.height <= 0) {
         std::cerr << "pt_render: --W and --H must be positive" << std::endl;
         return 2;
