@@ -34,7 +34,7 @@ def _render(L, d, name, W, H, rows, slices, mrr, error, seed, sky=None):
     return out
 
 
-@pytest.mark.parametrize("case", range(14))
+@pytest.mark.parametrize("case", range(14 + int(os.environ.get("PT_SCHED_EXTRA", "0"))))      # PT_SCHED_EXTRA=n: a soak with n more launches
 def test_random_launches_against_the_plainest_configuration(tmp_path, case):
     import make_open_scene as MO
     import make_replicated_scene as MR
