@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -72,7 +72,16 @@ typedef struct pt_render_params {
     float error;                    /* -ERR            config.h:23 (adaptive sampling threshold; <0 disables) */
     uint32_t seed;                  /* -SEED           config.h:10 */
     int32_t rng_policy;             /* PT_RNG_COUNTER (0, the default of a zeroed struct) or PT_RNG_REFERENCE_STREAM */
+    int32_t row_stride;             /* 0 or 1: the band is rows [row_begin, row_end).  n > 1: the band is every n-th TILE ROW of 8 image rows,
+                                     * starting with rows row_begin .. row_begin + 7 (row_begin a multiple of 8), as far as they lie below
+                                     * row_end; the buffers hold those tile rows packed, 8 rows each (pt_band_rows() rows in all; rows of the
+                                     * last tile row at or beyond row_end are left untouched).  The interleaved split of a frame over the
+                                     * devices of a node: device k of n takes row_begin = 8 k, row_stride = n, row_end = height -- every
+                                     * device then sees the same mix of cheap and expensive rows (pt_frame_* does this itself). */
 } pt_render_params;
+
+/* Rows the sum / sum2 / count buffers of a call with these parameters hold: row_end - row_begin, or with a row stride 8 per tile row. */
+int32_t pt_band_rows(const pt_render_params *params);
 
 /* Random-number policies.
  * PT_RNG_COUNTER: stateless Philox4x32-10 keyed by (seed, global pixel, pass, segment) -- the policy the device
@@ -154,10 +163,13 @@ int pt_render_host(pt_scene *scene, const pt_render_params *params, float *sum, 
 /* A render session keeps one row band's accumulators ON THE DEVICE between calls: the progressive driver
  * (main.cpp:110-160: a preview every `update` passes, the -TL check before every pass) adds pass slices with
  * pt_session_render and reads the band back only when it needs a preview or the final image.
- * params->width/height/row_begin/row_end must equal the session's; pass_begin/pass_count select the slice. */
+ * params->width/height/row_begin/row_end (and row_stride) must equal the session's; pass_begin/pass_count select the slice. */
 typedef struct pt_session pt_session;
 int pt_session_create(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end,
                       pt_session **out);                       /* accumulators start at zero */
+/* the same for an interleaved band (pt_render_params::row_stride; 0 / 1 = pt_session_create): params->row_stride must equal it */
+int pt_session_create_strided(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, int32_t row_stride,
+                              pt_session **out);
 int pt_session_render(pt_session *session, const pt_render_params *params, pt_render_stats *stats);
 int pt_session_wait(pt_session *session);                                           /* until every slice queued so far is done */
 int pt_session_read(pt_session *session, float *sum, float *sum2, int32_t *count);   /* waits, then copies out */
@@ -167,12 +179,17 @@ void pt_session_destroy(pt_session *session);
 /* ---- one image on several GPUs --------------------------------------------------------------------- */
 
 /* The reference splits the image's rows over its OpenMP threads inside the pass loop (main.cpp:115,132,141); a pt_frame splits
- * them over DEVICES: n_bands contiguous row bands (band b on devices[b]; they differ by at most one row), every band a
- * pt_session on its device.  pt_frame_render enqueues a pass slice on every device before it waits for anything;
+ * them over DEVICES: n_bands bands (band b on devices[b]), every band a pt_session on its device.  The split is INTERLEAVED: band
+ * b is every n_bands-th tile row of 8 image rows from rows 8 b on (pt_render_params::row_stride), so that every device renders
+ * the same mix of cheap and expensive rows -- contiguous bands of the 3840 x 2160 Tor.obj frame cost 67 ... 90 ms in four and
+ * 34 ... 46 ms in eight, and a frame is as slow as its slowest band.  (An image with fewer tile rows than bands keeps contiguous
+ * bands, which differ by at most one row.)  pt_frame_render enqueues a pass slice on every device before it waits for anything;
  * pt_frame_gather brings the bands' accumulators (28 bytes per pixel) to the root device devices[0] with ONE RCCL group of
- * ncclSend / ncclRecv pairs, received straight into the root's full-frame planes (the root's own band renders into those
- * planes directly and is never copied); pt_frame_read copies the full frame to the host, where the unmodified pt_resolve
- * runs.  The result is bit-identical to the one-device frame for any n_bands (the RNG is keyed by the global pixel index).
+ * ncclSend / ncclRecv pairs -- each band's planes in one piece, into a staging buffer on the root, from where three strided device
+ * copies per band put the tile rows in place in the root's full-frame planes (contiguous bands are received straight into their
+ * rows, and the root's own band renders into the planes directly); pt_frame_read copies the full frame to the host, where the
+ * unmodified pt_resolve runs.  The result is bit-identical to the one-device frame for any n_bands (the RNG is keyed by the global
+ * pixel index).
  * `scene` is only read (any device, or host-only): the frame makes its own per-device copies, which share the parsed
  * model and the hierarchy.
  * flags: PT_FRAME_REHEARSE -- devices[] may name a device several times (the N-band code path on a one-GPU box); the
@@ -189,8 +206,11 @@ typedef struct pt_frame pt_frame;
 #define PT_FRAME_TRANSPORT_DEVICE_COPIES 2   /* rehearsal: hipMemcpyAsync / hipMemcpyPeerAsync */
 int pt_frame_create(const pt_scene *scene, const int32_t *devices, int32_t n_bands, int32_t width, int32_t height,
                     uint32_t flags, pt_frame **out);                                  /* accumulators start at zero */
-/* band_rows: 2 per band, [begin, end); band_device: 1 per band; any pointer may be NULL */
+/* band_rows: 2 per band, [begin, end) (interleaved split: [8 b, height) -- of which the band holds every row_stride-th tile row);
+ * band_device: 1 per band; any pointer may be NULL */
 int pt_frame_info(const pt_frame *frame, int32_t *n_bands, int32_t *band_rows, int32_t *band_device, int32_t *transport);
+/* 1: contiguous bands; n > 1: the interleaved split, band b = tile rows b, b + n, ... */
+int pt_frame_row_stride(const pt_frame *frame, int32_t *row_stride);
 /* params->width / height must equal the frame's, row_begin / row_end must be 0 / height (the frame owns the split);
  * pass_begin / pass_count select the slice.  Returns without waiting unless stats != NULL (then: sums over the bands,
  * kernel_ms = the slowest band's). */

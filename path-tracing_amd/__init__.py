@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "lib", "libpt_hip
 PT_OK = 0
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_IO", 3: "PT_ERR_PARSE", 4: "PT_ERR_NO_DEVICE",
                 5: "PT_ERR_HIP", 6: "PT_ERR_OUT_OF_MEMORY", 7: "PT_ERR_UNSUPPORTED"}
-PT_ABI_VERSION = 4
+PT_ABI_VERSION = 5
 RNG_COUNTER, RNG_REFERENCE_STREAM = 0, 1
 # test-only builds of the same ABI (csrc/Makefile): never loaded by the product path
 VERIFY_LIB_PATH = os.path.join(_HERE, "lib", "libpt_verify.so")
@@ -35,7 +35,8 @@ ABI_SYMBOLS = ["pt_scene_load_obj", "pt_scene_create", "pt_scene_counts", "pt_sc
                "pt_write_bmp", "pt_host_alloc", "pt_host_free", "pt_abi_version", "pt_device_count", "pt_last_error",
                "pt_scene_clone_to_device", "pt_scene_timings", "pt_table_limits_check", "pt_rccl_available",
                "pt_frame_create", "pt_frame_info", "pt_frame_render", "pt_frame_gather", "pt_frame_wait", "pt_frame_read",
-               "pt_frame_clear", "pt_frame_destroy", "pt_frame_band_kernel_ms", "pt_scene_skybox_size", "pt_table_limits_check_tree"]
+               "pt_frame_clear", "pt_frame_destroy", "pt_frame_band_kernel_ms", "pt_scene_skybox_size", "pt_table_limits_check_tree",
+               "pt_band_rows", "pt_session_create_strided", "pt_frame_row_stride"]
 FRAME_REHEARSE, FRAME_SELF_COLLECTIVE = 1, 2
 BIG_SCENE_TRIANGLES = 1024     # csrc/pt_scene.hpp: kBigSceneTriangles -- scenes above it take the box-tree path (tests/test_abi_host.py compares)
 TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "device_copies"}
@@ -50,7 +51,7 @@ class PtError(RuntimeError):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("pass_begin", C.c_int32), ("pass_count", C.c_int32), ("max_ray_reflections", C.c_int32),
-                ("eps", C.c_float), ("error", C.c_float), ("seed", C.c_uint32), ("rng_policy", C.c_int32)]
+                ("eps", C.c_float), ("error", C.c_float), ("seed", C.c_uint32), ("rng_policy", C.c_int32), ("row_stride", C.c_int32)]
 
 
 class RenderStats(C.Structure):
@@ -116,6 +117,9 @@ def load_library(path):
     L.pt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp, C.POINTER(RenderStats)]
     L.pt_render_host.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.POINTER(RenderStats)]
     L.pt_session_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.pt_session_create_strided.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.pt_band_rows.restype = C.c_int32
+    L.pt_band_rows.argtypes = [C.POINTER(RenderParams)]
     L.pt_session_render.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(RenderStats)]
     L.pt_session_read.argtypes = [vp, fp, fp, ip]
     L.pt_session_wait.argtypes = [vp]
@@ -150,6 +154,7 @@ def load_library(path):
     L.pt_frame_destroy.argtypes = [vp]
     L.pt_frame_destroy.restype = None
     L.pt_frame_band_kernel_ms.argtypes = [vp, fp]
+    L.pt_frame_row_stride.argtypes = [vp, ip]
     L.pt_scene_skybox_size.argtypes = [vp, ip, ip]
     L.pt_table_limits_check_tree.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]
     if hasattr(L, "pt_test_set_mutation"):
@@ -224,14 +229,14 @@ class Scene:
         return k
 
     def render_host(self, width, height, spp, mrr, *, eps=1e-4, error=-1.0, seed=42, rows=None, pass_begin=0,
-                    accum=None, want_stats=True, rng_policy=RNG_COUNTER):
+                    accum=None, want_stats=True, rng_policy=RNG_COUNTER, row_stride=0):
         r0, r1 = rows if rows is not None else (0, height)
-        n = (r1 - r0) * width
+        p = RenderParams(width, height, r0, r1, pass_begin, spp, mrr, eps, error, seed, rng_policy, row_stride)
+        n = band_rows(p, self._L) * width
         if accum is None:
             s, s2, c = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
         else:
             s, s2, c = accum
-        p = RenderParams(width, height, r0, r1, pass_begin, spp, mrr, eps, error, seed, rng_policy)
         st = RenderStats()
         _check(self._L.pt_render_host(self._h, C.byref(p), _fp(s), _fp(s2), _ip(c), C.byref(st) if want_stats else None), self._L)
         return s, s2, c, st.as_dict()
@@ -311,24 +316,40 @@ class Scene:
             pass
 
 
+def band_rows(params, L=None):
+    """Rows the accumulator buffers of a call with these RenderParams hold (pt_band_rows)."""
+    return (L or lib()).pt_band_rows(C.byref(params))
+
+
+def interleaved_rows(height, row_begin, row_stride):
+    """Image rows, in buffer order, of the interleaved band (row_begin, height, row_stride): -1 for buffer rows beyond the image."""
+    out = []
+    for t0 in range(row_begin, height, 8 * max(1, row_stride)):
+        out += [y if y < height else -1 for y in range(t0, t0 + 8)]
+    return np.array(out, np.int64)
+
+
 class Session:
     """pt_session: one row band's accumulators kept on the device between pass slices (progressive driver)."""
 
-    def __init__(self, scene, width, height, rows=None):
+    def __init__(self, scene, width, height, rows=None, row_stride=0):
         r0, r1 = rows if rows is not None else (0, height)
         self._scene, self._L = scene, scene._L
-        self.width, self.height, self.rows = width, height, (r0, r1)
+        self.width, self.height, self.rows, self.row_stride = width, height, (r0, r1), row_stride
         self._h = C.c_void_p()
-        _check(self._L.pt_session_create(scene._h, width, height, r0, r1, C.byref(self._h)), self._L)
+        if row_stride > 1:
+            _check(self._L.pt_session_create_strided(scene._h, width, height, r0, r1, row_stride, C.byref(self._h)), self._L)
+        else:
+            _check(self._L.pt_session_create(scene._h, width, height, r0, r1, C.byref(self._h)), self._L)
 
     def render(self, pass_begin, pass_count, mrr, *, eps=1e-4, error=-1.0, seed=42, want_stats=False):
-        p = RenderParams(self.width, self.height, self.rows[0], self.rows[1], pass_begin, pass_count, mrr, eps, error, seed, 0)
+        p = RenderParams(self.width, self.height, self.rows[0], self.rows[1], pass_begin, pass_count, mrr, eps, error, seed, 0, self.row_stride)
         st = RenderStats()
         _check(self._L.pt_session_render(self._h, C.byref(p), C.byref(st) if want_stats else None), self._L)
         return st.as_dict() if want_stats else None
 
     def read(self):
-        n = (self.rows[1] - self.rows[0]) * self.width
+        n = band_rows(RenderParams(self.width, self.height, self.rows[0], self.rows[1], 0, 0, 0, 0, 0, 0, 0, self.row_stride), self._L) * self.width
         s, s2, c = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
         _check(self._L.pt_session_read(self._h, _fp(s), _fp(s2), _ip(c)), self._L)
         return s, s2, c
@@ -379,7 +400,10 @@ class Frame:
         _check(self._L.pt_frame_info(self._h, C.byref(n), None, None, None), self._L)
         rows, dev, tr = np.zeros(2 * n.value, np.int32), np.zeros(n.value, np.int32), C.c_int32()
         _check(self._L.pt_frame_info(self._h, C.byref(n), _ip(rows), _ip(dev), C.byref(tr)), self._L)
-        return {"bands": n.value, "rows": rows.reshape(-1, 2).tolist(), "devices": dev.tolist(), "transport": TRANSPORT_NAMES[tr.value]}
+        stride = C.c_int32()
+        _check(self._L.pt_frame_row_stride(self._h, C.byref(stride)), self._L)
+        return {"bands": n.value, "rows": rows.reshape(-1, 2).tolist(), "devices": dev.tolist(), "transport": TRANSPORT_NAMES[tr.value],
+                "row_stride": stride.value}
 
     def render(self, pass_begin, pass_count, mrr, *, eps=1e-4, error=-1.0, seed=42, want_stats=False):
         p = RenderParams(self.width, self.height, 0, self.height, pass_begin, pass_count, mrr, eps, error, seed, 0)

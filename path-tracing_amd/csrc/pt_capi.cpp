@@ -265,6 +265,8 @@ int enqueue_render(pt_scene *scene, LaunchCtx &ctx, const pt_render_params *p, f
     a.sum2 = d_sum2;
     a.count = d_count;
     a.width = p->width; a.height = p->height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+    a.row_stride = std::max(1, p->row_stride);
+    a.band_rows = ptc::band_rows(p);
     a.regen_min_dead = pt::regen_min_dead_for(p->max_ray_reflections);
 #ifdef PT_TEST_HOOKS
     if (g_regen_min_dead > 0) a.regen_min_dead = static_cast<uint32_t>(g_regen_min_dead);
@@ -405,12 +407,22 @@ int collect_stats(pt_scene *scene, LaunchCtx &ctx, hipStream_t stream, pt_render
 
 namespace ptc {
 
+// Rows the accumulator planes of a call hold: the band's rows, or with a row stride eight per tile row of the band.
+int32_t band_rows(const pt_render_params *p) {
+    const int32_t rows = p->row_end - p->row_begin;
+    if (p->row_stride <= 1 || rows <= 0) return rows;
+    const int32_t period = 8 * p->row_stride;
+    return 8 * ((rows + period - 1) / period);
+}
+
 int check_params(const pt_scene *scene, const pt_render_params *p) {
     if (!scene || !p) return fail(PT_ERR_INVALID_ARGUMENT, "null scene or params");
     if (scene->device < 0) return fail(PT_ERR_NO_DEVICE, "scene was created without a device (device < 0)");
     if (p->width <= 0 || p->height <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "width and height must be positive");
     if (p->row_begin < 0 || p->row_end > p->height || p->row_begin > p->row_end)
         return fail(PT_ERR_INVALID_ARGUMENT, "row band outside the image");
+    if (p->row_stride < 0 || (p->row_stride > 1 && p->row_begin % 8 != 0))
+        return fail(PT_ERR_INVALID_ARGUMENT, "row_stride must be 0 / 1 (contiguous rows) or n > 1 with row_begin a multiple of 8 (every n-th tile row of 8 rows)");
     if (p->pass_begin < 0 || p->pass_count < 0) return fail(PT_ERR_INVALID_ARGUMENT, "negative pass range");
     if (static_cast<long long>(p->width) * p->height > 0x7fffffffLL)
         return fail(PT_ERR_INVALID_ARGUMENT, "image has more than 2^31 pixels");
@@ -422,19 +434,19 @@ int check_params(const pt_scene *scene, const pt_render_params *p) {
 }
 
 int session_create_on(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, float *d_sum,
-                      float *d_sum2, int32_t *d_count, pt_session **out) {
+                      float *d_sum2, int32_t *d_count, pt_session **out, int32_t row_stride) {
     if (!out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     pt_render_params p;
     std::memset(&p, 0, sizeof p);
-    p.width = width; p.height = height; p.row_begin = row_begin; p.row_end = row_end;
+    p.width = width; p.height = height; p.row_begin = row_begin; p.row_end = row_end; p.row_stride = row_stride;
     const int rc = check_params(scene, &p);
     if (rc != PT_OK) return rc;
     PT_HIP_TRY(hipSetDevice(scene->device));
     std::unique_ptr<pt_session> s(new pt_session);
     s->scene = scene;
-    s->width = width; s->height = height; s->row_begin = row_begin; s->row_end = row_end;
-    s->n = static_cast<size_t>(row_end - row_begin) * width;
+    s->width = width; s->height = height; s->row_begin = row_begin; s->row_end = row_end; s->row_stride = std::max(1, row_stride);
+    s->n = static_cast<size_t>(band_rows(&p)) * width;
     PT_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     hipError_t e = hipSuccess;
     if (d_sum) {   // borrowed planes: the caller zeroes and frees them
@@ -458,7 +470,8 @@ int session_create_on(pt_scene *scene, int32_t width, int32_t height, int32_t ro
 
 int session_enqueue(pt_session *s, const pt_render_params *p, bool want_stats) {
     if (!s || !p) return fail(PT_ERR_INVALID_ARGUMENT, "null session or params");
-    if (p->width != s->width || p->height != s->height || p->row_begin != s->row_begin || p->row_end != s->row_end)
+    if (p->width != s->width || p->height != s->height || p->row_begin != s->row_begin || p->row_end != s->row_end ||
+        std::max(1, p->row_stride) != s->row_stride)
         return fail(PT_ERR_INVALID_ARGUMENT, "params describe another band than the session's");
     const int rc = check_params(s->scene, p);
     if (rc != PT_OK) return rc;
@@ -729,7 +742,7 @@ static int render_host_impl(pt_scene *scene, const pt_render_params *p, float *s
     if (rc != PT_OK) return rc;
     if (!sum || !sum2 || !count) return fail(PT_ERR_INVALID_ARGUMENT, "null accumulator pointer");
     PT_HIP_TRY(hipSetDevice(scene->device));
-    const int rows = p->row_end - p->row_begin;
+    const int rows = ptc::band_rows(p);
     const size_t W = static_cast<size_t>(p->width), n = static_cast<size_t>(rows) * W;
     if (n == 0) {
         if (stats) zero_stats(scene, stats);
@@ -1055,8 +1068,15 @@ int pt_render_host(pt_scene *scene, const pt_render_params *p, float *sum, float
     return guarded([&] { return render_host_impl(scene, p, sum, sum2, count, stats); });
 }
 
+int32_t pt_band_rows(const pt_render_params *params) { return params ? ptc::band_rows(params) : 0; }
+
+int pt_session_create_strided(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, int32_t row_stride,
+                              pt_session **out) {
+    return guarded([&] { return ptc::session_create_on(scene, width, height, row_begin, row_end, nullptr, nullptr, nullptr, out, row_stride); });
+}
+
 int pt_session_create(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, pt_session **out) {
-    return guarded([&] { return ptc::session_create_on(scene, width, height, row_begin, row_end, nullptr, nullptr, nullptr, out); });
+    return guarded([&] { return ptc::session_create_on(scene, width, height, row_begin, row_end, nullptr, nullptr, nullptr, out, 1); });
 }
 
 int pt_session_render(pt_session *session, const pt_render_params *params, pt_render_stats *stats) {

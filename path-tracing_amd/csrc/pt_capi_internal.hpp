@@ -85,7 +85,7 @@ struct pt_scene {
 // A row band's accumulators kept on the device between pass slices (pt_session_*).
 struct pt_session {
     pt_scene *scene = nullptr;
-    int32_t width = 0, height = 0, row_begin = 0, row_end = 0;
+    int32_t width = 0, height = 0, row_begin = 0, row_end = 0, row_stride = 1;
     size_t n = 0;                 // pixels of the band
     float *d_band = nullptr;      // owned: sum[3n] | sum2[3n] | count[n], each plane 256-byte aligned; nullptr if the planes are borrowed
     float *d_sum = nullptr, *d_sum2 = nullptr;
@@ -121,7 +121,9 @@ int guarded(F &&f) noexcept {
 int check_params(const pt_scene *scene, const pt_render_params *p);
 // A session whose planes live in memory the caller owns (the root band of a frame renders straight into the frame's planes).
 int session_create_on(pt_scene *scene, int32_t width, int32_t height, int32_t row_begin, int32_t row_end, float *d_sum,
-                      float *d_sum2, int32_t *d_count, pt_session **out);
+                      float *d_sum2, int32_t *d_count, pt_session **out, int32_t row_stride = 1);
+// rows the accumulator planes of a call hold (pt_band_rows)
+int32_t band_rows(const pt_render_params *p);
 // pt_session_render in two halves: enqueue the slice (never waits for the device), then -- if statistics were asked for --
 // wait for it and read them.  A frame enqueues on every device before it waits on any.
 int session_enqueue(pt_session *s, const pt_render_params *p, bool want_stats);

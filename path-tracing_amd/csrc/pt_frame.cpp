@@ -2,13 +2,20 @@
 //
 // The reference splits the rows of the image over its OpenMP threads inside main()'s pass loop (main.cpp:115,132,141:
 // `#pragma omp parallel for` over y) and every thread writes its rows of the shared accumulators.  Here the "threads" are
-// devices: the image is cut into contiguous row bands, each band has a pt_session on its device (the scene's tables are
-// copied to every device, the model is parsed and its hierarchy built once), a pass slice is enqueued on ALL devices before
-// anything waits, and the accumulators of the bands are brought together on the root device by ONE RCCL group of
-// send / receive pairs over xGMI: 28 bytes per pixel, three planes per band, received straight into the
-// rows they belong to in the root's full-frame planes.  The root's own band renders into those planes directly, so it is
-// never copied.  The counter RNG is keyed by the GLOBAL pixel index (pt_kernels.hip), so the frame is bit-identical to the
-// one-device frame for any number of bands.
+// devices: the image's rows are split into bands, each band has a pt_session on its device (the scene's tables are copied to
+// every device, the model is parsed and its hierarchy built once), a pass slice is enqueued on ALL devices before anything
+// waits, and the accumulators of the bands are brought together on the root device by ONE RCCL group of send / receive pairs
+// over xGMI: 28 bytes per pixel, three planes per band.  The counter RNG is keyed by the GLOBAL pixel index
+// (pt_kernels.hip), so the frame is bit-identical to the one-device frame for any number of bands.
+//
+// The split is INTERLEAVED (round 4): band b of n is every n-th tile row of 8 image rows, starting with rows 8 b ... (one launch per
+// band: pt_render_params::row_stride).  Contiguous bands -- the split of rounds 1-3, and what the reference's static OpenMP schedule
+// gives its threads -- cost unequal amounts: on the 3840 x 2160 frame cut in four, the bands through the torus took 90 and 78 ms, the
+// outer ones 67 and 68 (in eight: 33.7 ... 45.8 ms), and a frame is as slow as its slowest band; interleaved, every device sees the same
+// mix of rows.  A band's planes hold its tile rows packed, so the gather moves each band to the root in one piece per plane (into
+// a staging buffer there) and three strided device copies per band put the tile rows where they belong in the root's full-frame
+// planes.  Images with fewer tile rows than bands keep contiguous bands (received straight into their rows; the root's own band then
+// renders into the planes directly).
 //
 // RCCL is used directly (ncclCommInitAll / ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd), no framework in between.
 // librccl.so is opened on first use: a one-device frame never loads it (it is a 570 MB library).
@@ -90,8 +97,13 @@ int rccl_fail(ncclResult_t e, const char *what) {
 struct FrameXfer {
     int band;
     const void *src;
-    void *dst;
+    void *dst;        // contiguous bands: the band's rows in the root's frame planes; interleaved: the band's staging plane on the root
     size_t words;
+    // interleaved split: where the staged plane's tile rows go (strided copy on the root after the transfer); 0 = none
+    void *scatter_dst = nullptr;      // row 8 b of the root plane
+    size_t tile_row_bytes = 0;        // 8 rows of the plane
+    size_t full_tile_rows = 0;        // tile rows copied whole
+    size_t tail_bytes = 0;            // rows of the band's last tile row that lie inside the image (0: it is whole too)
 };
 
 struct pt_frame {
@@ -99,7 +111,9 @@ struct pt_frame {
     uint32_t flags = 0;
     int transport = PT_FRAME_TRANSPORT_NONE;
     std::vector<int> band_device;          // per band
-    std::vector<int32_t> band_rows;        // 2 per band: [begin, end)
+    std::vector<int32_t> band_rows;        // 2 per band: [begin, end) (interleaved split: [8 b, height), every row_stride-th tile row)
+    int32_t row_stride = 1;                // 1: contiguous bands; n > 1: interleaved tile rows
+    float *d_staging = nullptr;            // root device, interleaved split: the bands' planes as they arrive, before the scatter
     std::vector<int> devices;              // distinct devices, devices[0] = root
     std::vector<pt_scene *> scenes;        // one per distinct device (owned)
     std::vector<int> band_scene;           // band -> index into scenes / devices
@@ -158,8 +172,14 @@ int frame_create_impl(const pt_scene *scene, const int32_t *devices, int32_t n_b
         f->band_scene.push_back(static_cast<int>(it - f->devices.begin()));
         if (it == f->devices.end()) f->devices.push_back(d);
         f->band_device.push_back(d);
+    }
+    // the split: interleaved tile rows when every band gets at least one, contiguous bands otherwise (tiny images)
+    const int32_t tile_rows = (height + 7) / 8;
+    f->row_stride = (n_bands > 1 && tile_rows >= n_bands) ? n_bands : 1;
+    for (int b = 0; b < n_bands; ++b) {
         int32_t r0, r1;
-        band_rows_of(height, n_bands, b, r0, r1);
+        if (f->row_stride > 1) { r0 = 8 * b; r1 = height; }
+        else band_rows_of(height, n_bands, b, r0, r1);
         f->band_rows.push_back(r0);
         f->band_rows.push_back(r1);
     }
@@ -183,14 +203,19 @@ int frame_create_impl(const pt_scene *scene, const int32_t *devices, int32_t n_b
     // sessions.  Band 0 (the root's) renders into the frame planes themselves; with the RCCL transport every other band is on
     // another device and has its own buffer; a rehearsal gives EVERY other band its own buffer, also on the root device, so
     // that the N-band gather really moves N - 1 bands.
+    // (interleaved split: every band, the root's too, renders into packed planes of its own; bands on other devices are staged on
+    // the root before their tile rows are put in place)
+    const bool interleaved = f->row_stride > 1;
+    size_t staging_floats = 0;
     for (int b = 0; b < n_bands; ++b) {
         const int32_t r0 = f->band_rows[2 * b], r1 = f->band_rows[2 * b + 1];
         const size_t first = static_cast<size_t>(r0) * width;
-        const bool on_planes = b == 0 && !self_coll;
+        const bool on_planes = !interleaved && b == 0 && !self_coll;
         pt_session *ses = nullptr;
         const int rc = on_planes ? ptc::session_create_on(f->scenes[f->band_scene[b]], width, height, r0, r1, f->root_sum() + 3 * first,
                                                           f->root_sum2() + 3 * first, f->root_count() + first, &ses)
-                                 : ptc::session_create_on(f->scenes[f->band_scene[b]], width, height, r0, r1, nullptr, nullptr, nullptr, &ses);
+                                 : ptc::session_create_on(f->scenes[f->band_scene[b]], width, height, r0, r1, nullptr, nullptr, nullptr, &ses,
+                                                          f->row_stride);
         if (rc != PT_OK) return rc;
         f->sessions.push_back(ses);
         f->band_on_root_planes.push_back(on_planes ? 1 : 0);
@@ -198,11 +223,41 @@ int frame_create_impl(const pt_scene *scene, const int32_t *devices, int32_t n_b
             f->xfers.push_back({b, ses->d_sum, f->root_sum() + 3 * first, 3 * ses->n});
             f->xfers.push_back({b, ses->d_sum2, f->root_sum2() + 3 * first, 3 * ses->n});
             f->xfers.push_back({b, ses->d_count, f->root_count() + first, ses->n});
+            if (interleaved) {
+                // band b holds tile rows b, b + n, ...: all whole except possibly the image's last one
+                const size_t count = (static_cast<size_t>(tile_rows) - b + f->row_stride - 1) / f->row_stride;
+                const bool has_last = (static_cast<size_t>(b) + (count - 1) * f->row_stride) == static_cast<size_t>(tile_rows) - 1;
+                const size_t last_rows = static_cast<size_t>(height) - 8u * (static_cast<size_t>(tile_rows) - 1);
+                const bool partial = has_last && last_rows < 8;
+                const bool staged = f->band_device[b] != root;
+                for (int k = 0; k < 3; ++k) {
+                    FrameXfer &x = f->xfers[f->xfers.size() - 3 + k];
+                    const size_t elem = k < 2 ? 12 : 4;      // bytes per pixel of the plane
+                    x.scatter_dst = x.dst;                   // row 8 b of the root plane
+                    x.tile_row_bytes = 8u * static_cast<size_t>(width) * elem;
+                    x.full_tile_rows = partial ? count - 1 : count;
+                    x.tail_bytes = partial ? last_rows * static_cast<size_t>(width) * elem : 0;
+                    x.dst = nullptr;                         // set below for staged bands
+                    if (staged) {
+                        x.dst = reinterpret_cast<void *>(staging_floats + 1);    // (offset + 1 until the buffer exists)
+                        staging_floats += (x.words + 63) / 64 * 64;
+                    }
+                }
+            }
         }
+    }
+    if (interleaved) {
+        PT_HIP_TRY(hipSetDevice(root));
+        if (staging_floats > 0) {
+            PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&f->d_staging), staging_floats * sizeof(float)));
+            for (FrameXfer &x : f->xfers)
+                if (x.dst) x.dst = f->d_staging + (reinterpret_cast<size_t>(x.dst) - 1);
+        }
+        if (!f->gather_stream) PT_HIP_TRY(hipStreamCreateWithFlags(&f->gather_stream, hipStreamNonBlocking));   // staged bands are put in place on it
     }
     if (f->transport == PT_FRAME_TRANSPORT_RCCL) {
         PT_HIP_TRY(hipSetDevice(root));
-        PT_HIP_TRY(hipStreamCreateWithFlags(&f->gather_stream, hipStreamNonBlocking));   // the receives of the gather
+        if (!f->gather_stream) PT_HIP_TRY(hipStreamCreateWithFlags(&f->gather_stream, hipStreamNonBlocking));   // the receives of the gather
         Rccl &r = rccl();
         if (!r.error.empty()) return fail(PT_ERR_UNSUPPORTED, r.error);
         f->comms.assign(f->devices.size(), nullptr);
@@ -226,6 +281,7 @@ int frame_render_impl(pt_frame *f, const pt_render_params *p, pt_render_stats *s
         pt_render_params bp = *p;
         bp.row_begin = f->band_rows[2 * b];
         bp.row_end = f->band_rows[2 * b + 1];
+        bp.row_stride = f->row_stride;
         const int rc = ptc::session_enqueue(f->sessions[b], &bp, stats != nullptr);
         if (rc != PT_OK) return rc;
     }
@@ -258,15 +314,38 @@ int frame_gather_impl(pt_frame *f) {
         f->dirty = false;
         return PT_OK;
     }
+    const int root = f->devices[0];
+    // interleaved split: a band's packed plane -> its tile rows in the root's plane (every row_stride-th), on `stream` of the root device
+    auto scatter = [&](const FrameXfer &x, const void *plane, hipStream_t stream) -> int {
+        const size_t pitch = static_cast<size_t>(f->row_stride) * x.tile_row_bytes;
+        if (x.full_tile_rows > 0)
+            PT_HIP_TRY(hipMemcpy2DAsync(x.scatter_dst, pitch, plane, x.tile_row_bytes, x.tile_row_bytes, x.full_tile_rows, hipMemcpyDeviceToDevice, stream));
+        if (x.tail_bytes > 0)
+            PT_HIP_TRY(hipMemcpyAsync(static_cast<char *>(x.scatter_dst) + x.full_tile_rows * pitch,
+                                      static_cast<const char *>(plane) + x.full_tile_rows * x.tile_row_bytes, x.tail_bytes, hipMemcpyDeviceToDevice, stream));
+        return PT_OK;
+    };
     if (f->transport == PT_FRAME_TRANSPORT_DEVICE_COPIES) {
         // rehearsal: the collective's transfers as plain copies, each on its band's stream (after that band's kernels)
         for (const FrameXfer &x : f->xfers) {
             pt_session *s = f->sessions[x.band];
             PT_HIP_TRY(hipSetDevice(s->scene->device));
-            if (s->scene->device == f->devices[0])
+            if (x.scatter_dst) {
+                if (s->scene->device == root) {
+                    const int rc = scatter(x, x.src, s->stream);
+                    if (rc != PT_OK) return rc;
+                } else {   // staged on the root, then put in place there once the copy has arrived
+                    PT_HIP_TRY(hipMemcpyPeerAsync(x.dst, root, x.src, s->scene->device, x.words * 4, s->stream));
+                    PT_HIP_TRY(hipStreamSynchronize(s->stream));      // (a rehearsal across devices: not a path anything times)
+                    PT_HIP_TRY(hipSetDevice(root));
+                    const int rc = scatter(x, x.dst, f->gather_stream);
+                    if (rc != PT_OK) return rc;
+                }
+            } else if (s->scene->device == root) {
                 PT_HIP_TRY(hipMemcpyAsync(x.dst, x.src, x.words * 4, hipMemcpyDeviceToDevice, s->stream));
-            else
-                PT_HIP_TRY(hipMemcpyPeerAsync(x.dst, f->devices[0], x.src, s->scene->device, x.words * 4, s->stream));
+            } else {
+                PT_HIP_TRY(hipMemcpyPeerAsync(x.dst, root, x.src, s->scene->device, x.words * 4, s->stream));
+            }
         }
         f->dirty = false;
         return PT_OK;
@@ -279,6 +358,7 @@ int frame_gather_impl(pt_frame *f) {
     for (const FrameXfer &x : f->xfers) {
         pt_session *s = f->sessions[x.band];
         const int rank = f->band_scene[x.band];
+        if (x.scatter_dst && !x.dst) continue;       // interleaved split, a band on the root device: no transfer, only the scatter below
         ncclResult_t e = r.Send(x.src, x.words, ncclFloat32, 0, f->comms[rank], s->stream);
         if (e == ncclSuccess) e = r.Recv(x.dst, x.words, ncclFloat32, rank, f->comms[0], f->gather_stream);
         if (e != ncclSuccess && first_error == ncclSuccess) first_error = e;
@@ -286,6 +366,14 @@ int frame_gather_impl(pt_frame *f) {
     const ncclResult_t ge = r.GroupEnd();
     if (first_error != ncclSuccess) return rccl_fail(first_error, "ncclSend / ncclRecv");
     if (ge != ncclSuccess) return rccl_fail(ge, "ncclGroupEnd");
+    // interleaved split: the staged planes' tile rows into place -- on the gather stream, behind the receives; the root's own band from
+    // its buffer on its own stream, behind its kernels
+    for (const FrameXfer &x : f->xfers) {
+        if (!x.scatter_dst) continue;
+        PT_HIP_TRY(hipSetDevice(root));
+        const int rc = x.dst ? scatter(x, x.dst, f->gather_stream) : scatter(x, x.src, f->sessions[x.band]->stream);
+        if (rc != PT_OK) return rc;
+    }
     f->dirty = false;
     return PT_OK;
 }
@@ -358,6 +446,12 @@ int pt_frame_info(const pt_frame *f, int32_t *n_bands, int32_t *band_rows, int32
     return PT_OK;
 }
 
+int pt_frame_row_stride(const pt_frame *f, int32_t *row_stride) {
+    if (!f || !row_stride) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *row_stride = f->row_stride;
+    return PT_OK;
+}
+
 int pt_frame_band_kernel_ms(const pt_frame *f, float *ms) {
     if (!f || !ms) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     for (size_t b = 0; b < f->sessions.size(); ++b) ms[b] = b < f->band_kernel_ms.size() ? f->band_kernel_ms[b] : -1.0f;
@@ -405,6 +499,7 @@ void pt_frame_destroy(pt_frame *f) {
             (void)hipStreamDestroy(f->gather_stream);
         }
         if (f->d_frame) (void)hipFree(f->d_frame);
+        if (f->d_staging) (void)hipFree(f->d_staging);
     }
     for (pt_scene *s : f->scenes) pt_scene_destroy(s);
     delete f;

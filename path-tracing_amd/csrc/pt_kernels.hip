@@ -1547,10 +1547,16 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
         __builtin_amdgcn_wave_barrier();
     }
     // a.blocks_x counts tiles of THIS instantiation's width (the host asks integrator_tile_width)
-    int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTW, tile_y0 = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;   // wave-uniform
+    // A band is rows [row_begin, row_end) of the image -- or, with row_stride n > 1, every n-th TILE ROW (kTileH image rows) from row_begin
+    // on, packed in the band's planes: tile row j of the band is image rows row_begin + j n kTileH ..., plane rows j kTileH ...  (the
+    // interleaved split of a frame over several devices, pt_frame.cpp).  row0 = what to subtract from an image row to get its plane row.
+    const int tile_row = static_cast<int>(tile / a.blocks_x);
+    int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTW, tile_y0 = a.row_begin + tile_row * kTileH * a.row_stride;   // wave-uniform
+    int row0 = a.row_begin + tile_row * kTileH * (a.row_stride - 1);
     if constexpr (ADAPT != 0) {   // (the division runs on the vector unit: say that its results are scalars, or the 16 x 8 kernel spills one of them)
         tile_x0 = __builtin_amdgcn_readfirstlane(tile_x0);
         tile_y0 = __builtin_amdgcn_readfirstlane(tile_y0);
+        row0 = __builtin_amdgcn_readfirstlane(row0);
     }
     // pixel k of the lane: column (lane % 8) + 8 k of the tile, row lane / 8; its slot in the wave's LDS arrays is lane + 64 k
     int x[R];
@@ -1578,7 +1584,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (in_image[k]) {
-            const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + x[k];
+            const size_t p = static_cast<size_t>(y - row0) * a.width + x[k];
             const int id = lane + 64 * k;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -1607,7 +1613,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
             // (the answers of this instantiation live in LDS, by pixel: below)
         } else if constexpr (!kAccInLds) {
             if (in_image[k] && a.error >= 0.0f) {   // (adaptive sampling off: nobody asks, and a work item need not read its tile at all)
-                const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + x[k];
+                const size_t p = static_cast<size_t>(y - row0) * a.width + x[k];
                 lowvar[k] = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
             }
         } else {
@@ -1629,7 +1635,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
             const uint32_t j = static_cast<uint32_t>(lane) + 64u * kb;
             bool low = false;
             if (tile_x_of(j) < a.width && y < a.row_end) {
-                const size_t p = static_cast<size_t>(y - a.row_begin) * a.width + tile_x_of(j);
+                const size_t p = static_cast<size_t>(y - row0) * a.width + tile_x_of(j);
                 low = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
             }
             lds.low.v[j] = static_cast<uint16_t>((static_cast<uint32_t>(pass_first) << 1) | (low ? 1u : 0u));
@@ -1650,7 +1656,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
                 le = j & 63u;
                 kb = static_cast<int>(j >> 6);
             }
-            const size_t p = static_cast<size_t>(tile_y0 + static_cast<int>(le / kTileW) - a.row_begin) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * kb);
+            const size_t p = static_cast<size_t>(tile_y0 + static_cast<int>(le / kTileW) - row0) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * kb);
             n0 = a.sum[3 * p] + cr; n1 = a.sum[3 * p + 1] + cg; n2 = a.sum[3 * p + 2] + cb;
             p0 = a.sum2[3 * p] + cr * cr; p1 = a.sum2[3 * p + 1] + cg * cg; p2 = a.sum2[3 * p + 2] + cb * cb;
             nn = a.count[p] + 1;
@@ -2172,7 +2178,8 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
     // the tile is kTW*12 contiguous bytes of sum / sum2 and kTW*4 of count): dword stores at a 12-byte stride made the
     // memory side see about twice the bytes.  Column c of the tile's row r lives in LDS slot r*kTileW + c%kTileW + 64*(c/kTileW).
     if constexpr (kAccInLds) {
-    const int tile_x = static_cast<int>(tile % a.blocks_x) * kTW, tile_y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH;
+    const int tile_x = static_cast<int>(tile % a.blocks_x) * kTW, tile_y = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH * a.row_stride;
+    const int wb_row0 = a.row_begin + static_cast<int>(tile / a.blocks_x) * kTileH * (a.row_stride - 1);
     const bool whole = a.vec_ok && tile_x + kTW <= a.width && tile_y + kTileH <= a.row_end;   // wave-uniform
     wave_sync();
     auto slot_of = [](int row, int col) { return row * kTileW + (col % kTileW) + 64 * (col / kTileW); };
@@ -2183,7 +2190,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
             const int vv = v0 + lane;
             if (vv < kRowVec * kTileH) {
                 const int row = vv / kRowVec, v = vv % kRowVec;
-                const size_t base = (static_cast<size_t>(tile_y - a.row_begin + row) * a.width + tile_x) * 3 + 4 * v;
+                const size_t base = (static_cast<size_t>(tile_y - wb_row0 + row) * a.width + tile_x) * 3 + 4 * v;
                 float4 o1, o2;
                 float *p1 = &o1.x, *p2 = &o2.x;
 #pragma unroll
@@ -2199,7 +2206,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
         constexpr int kCntVec = kTW / 4;              // int4 per tile row of the count plane
         if (lane < kCntVec * kTileH) {
             const int row = lane / kCntVec, v = lane % kCntVec;
-            const size_t base = static_cast<size_t>(tile_y - a.row_begin + row) * a.width + tile_x + 4 * v;
+            const size_t base = static_cast<size_t>(tile_y - wb_row0 + row) * a.width + tile_x + 4 * v;
             int4 oc;
             oc.x = __float_as_int(lds.acc.v[6][slot_of(row, 4 * v)]);
             oc.y = __float_as_int(lds.acc.v[6][slot_of(row, 4 * v + 1)]);
@@ -2214,7 +2221,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
         for (int k = 0; k < R; ++k) {
             const int xe = tile_x + static_cast<int>(le % kTileW) + kTileW * k, ye = tile_y + static_cast<int>(le / kTileW);
             if (xe < a.width && ye < a.row_end) {
-                const size_t pe = static_cast<size_t>(ye - a.row_begin) * a.width + xe;
+                const size_t pe = static_cast<size_t>(ye - wb_row0) * a.width + xe;
                 const int id = lane + 64 * k;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -2404,7 +2411,7 @@ void integrator_plan_tiles(RenderArgs &args, int, int) {   // (the instrumented 
     args.narrow = 0;
     args.adapt_pool = 0;
     args.blocks_x = (args.width + kTileW * rays - 1) / (kTileW * rays);
-    args.n_tiles = static_cast<uint32_t>(args.blocks_x) * static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
+    args.n_tiles = static_cast<uint32_t>(args.blocks_x) * static_cast<uint32_t>((args.band_rows + kTileH - 1) / kTileH);
 }
 #else
 namespace {
@@ -2488,7 +2495,7 @@ hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream) {
 // underfilled, in which case its 8 x 8 variant runs (a tile's passes are a serial chain: fewer tiles than slots means idle SIMDs).
 void integrator_plan_tiles(RenderArgs &args, int cu_count, int force) {
     const bool sky = args.sky != nullptr, big = (args.big != 0), stats = launch_with_stats(args);
-    const uint32_t rows = static_cast<uint32_t>((args.row_end - args.row_begin + kTileH - 1) / kTileH);
+    const uint32_t rows = static_cast<uint32_t>((args.band_rows + kTileH - 1) / kTileH);      // tile rows of the band (its planes hold band_rows rows)
     int rays = (!sky && !stats) ? (big ? PT_BIG_RAYS_PER_LANE : PT_RAYS_PER_LANE) : 1;
     args.narrow = 0;
     args.adapt_pool = 0;

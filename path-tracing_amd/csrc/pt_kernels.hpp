@@ -39,6 +39,8 @@ struct RenderArgs {
     int32_t big;                 // CullTables::big: the hierarchy is the box tree (big-scene instantiations), not sphere trees
     uint32_t n_slots;            // slots of the hierarchy (>= n_tri: the box tree pads its leaves)
     int32_t width, height, row_begin, row_end;
+    int32_t row_stride;                 // 1: the band is rows [row_begin, row_end); n > 1: every n-th tile row (8 image rows) from row_begin on, below row_end
+    int32_t band_rows;                  // rows the band's planes hold (= row_end - row_begin without a stride; 8 per tile row with one)
     int32_t pass_begin, pass_count, mrr;
     float eps, error;
     uint32_t seed;
@@ -65,7 +67,7 @@ struct RenderArgs {
 hipError_t launch_integrator(const RenderArgs &args, hipStream_t stream);
 // waves of the instantiation such a launch runs that one compute unit holds at a time (runtime occupancy query, cached)
 hipError_t integrator_waves_per_cu(const RenderArgs &args, int *waves);
-// cuts the launch's row band (width, row_begin, row_end, scene, stats already set) into the tiles of the instantiation it will
+// cuts the launch's row band (width, row_begin, row_end, band_rows, scene, stats already set) into the tiles of the instantiation it will
 // run: fills narrow, adapt_pool, blocks_x and n_tiles
 // (force: 0 = by tile count, 1 = always 8 x 8 tiles, 2 = always 16 x 8, 3 = always 16 x 8 and 32 x 8 with adaptive sampling on: test builds)
 void integrator_plan_tiles(RenderArgs &args, int cu_count, int force = 0);

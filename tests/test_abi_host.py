@@ -28,12 +28,12 @@ def test_header_symbols_are_exported():
     assert declared == set(pt.ABI_SYMBOLS)
     for name in declared:
         assert getattr(pt.lib(), name) is not None
-    assert pt.lib().pt_abi_version() == 4 == pt.PT_ABI_VERSION
+    assert pt.lib().pt_abi_version() == 5 == pt.PT_ABI_VERSION
     assert not hasattr(pt.lib(), "pt_test_set_mutation")      # the test hooks exist only in the test builds
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(pt.RenderParams) == 44
+    assert C.sizeof(pt.RenderParams) == 48
     assert C.sizeof(pt.RenderStats) == 96
 
 

@@ -42,7 +42,7 @@ def test_one_band_frame_is_the_session_path(scene, single):
     (W, H, spp, mrr), ref = single
     f = pt.Frame(scene, [0], W, H)
     info = f.info()
-    assert info == {"bands": 1, "rows": [[0, H]], "devices": [0], "transport": "none"}
+    assert info == {"bands": 1, "rows": [[0, H]], "devices": [0], "transport": "none", "row_stride": 1}
     st = f.render(0, spp, mrr, error=0.001, seed=7, want_stats=True)
     assert _same(f.read(), ref)
     for k in ("samples_traced", "segments", "contributing", "misses"):
@@ -60,8 +60,12 @@ def test_rehearsed_bands_equal_one_band_bit_for_bit(scene, single, n_bands):
     info = f.info()
     assert info["bands"] == n_bands and info["transport"] == "device_copies" and info["devices"] == [0] * n_bands
     rows = info["rows"]
-    assert rows[0][0] == 0 and rows[-1][1] == H and all(rows[i][1] == rows[i + 1][0] for i in range(n_bands - 1))
-    assert max(b - a for a, b in rows) - min(b - a for a, b in rows) <= 1
+    if n_bands <= (H + 7) // 8:      # the interleaved split: band b = tile rows b, b + n, ... of the 7 this image has
+        assert info["row_stride"] == n_bands and rows == [[8 * b, H] for b in range(n_bands)]
+    else:                            # more bands than tile rows: contiguous bands that differ by at most a row
+        assert info["row_stride"] == 1
+        assert rows[0][0] == 0 and rows[-1][1] == H and all(rows[i][1] == rows[i + 1][0] for i in range(n_bands - 1))
+        assert max(b - a for a, b in rows) - min(b - a for a, b in rows) <= 1
     # pass slices with a gather in between (a preview), adaptive sampling on: decisions depend on earlier passes of the band
     f.render(0, 5, mrr, error=0.001, seed=7)
     f.gather()
