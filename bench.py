@@ -8,15 +8,16 @@
 Without WORLD_SIZE in the environment `--gpus N` starts its own N rank processes (one per GPU, RCCL) and prints rank
 0's line; under torch.distributed.run it is one of the ranks.
 
-One "step" = one complete frame: zero the accumulators, trace every sample of every pixel of this rank's row band
+One "step" = one complete frame: zero the accumulators, trace every sample of every pixel of this rank's band of rows
 (all passes x segments x triangles in one kernel launch through the C ABI), and -- for N > 1 -- the single RCCL
 gather of the accumulator bands to rank 0 (issued asynchronously: it overlaps the next frame's kernel, every gather is
 complete before the timed region ends).  At N = 1 the frame is the configuration north_star quotes its target on:
 models/Tor.obj, 1920x1080, 256 spp, -MRR 8, adaptive sampling off (-ERR -1, so all W*H*spp samples are traced;
 `--spp 64` is BASELINE configs[1], `--spp 1024` configs[2]).  For N > 1 the image grows with N
-(path-tracing_amd/bands.py: frame_for) so that every GPU keeps a 1080p-sized band: weak scaling, `value`.  Next to it
-every run also times BASELINE configs[3] as written -- 3840x2160 x 256 spp cut into N row bands, one gather -- and
-reports it as `configs3_strong` (strong scaling: the frame is fixed, 2160/N rows per GPU).
+(path-tracing_amd/bands.py: frame_for) so that every GPU keeps a 1080p-sized share: weak scaling, `value`.  Rank k of N renders
+every N-th tile row of 8 image rows (an interleaved split, pt_render_params::row_stride: contiguous bands cost unequal amounts,
+bands.py).  Next to it every run also times BASELINE configs[3] as written -- 3840x2160 x 256 spp split over the N ranks, one
+gather -- and reports it as `configs3_strong` (strong scaling: the frame is fixed, 2160/N rows per GPU).
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   roofline      the integrator kernel against the roofline that bounds it, vector-ALU issue (the path is
@@ -463,10 +464,9 @@ def main():
     diagnosis = []      # N > 1: one entry per run_frames call
 
     def run_frames(sc, W, H, spp, steps, warmup, error=-1.0):
-        """Renders `warmup` untimed and `steps` timed frames of a W x H x spp image cut into `world` row bands; returns
+        """Renders `warmup` untimed and `steps` timed frames of a W x H x spp image split over `world` ranks (bands.split); returns
         wall seconds (max over ranks), per-step kernel times of this rank, the frame's counters and the gathered frame."""
-        r0, r1 = bands.band_rows(H, world, rank)
-        rows = r1 - r0
+        r0, r1, row_stride, rows = bands.split(H, world, rank)      # rank k of N: every N-th tile row of 8 image rows, packed (N = 1: the frame)
         npx = rows * W
         # one contiguous band buffer: sum[3n] | sum2[3n] | count[n] (int32 bits) -> a single gather moves everything.
         # Two of them for N > 1: frame k is rendered into one while the gather of frame k-1 still reads the other, so the
@@ -475,7 +475,7 @@ def main():
         band_bufs = [torch.zeros(bands.band_floats(W, rows), dtype=torch.float32, device=dev) for _ in range(n_band)]
         recv_bufs = [None] * n_band     # rank 0: receive buffers, one set per band buffer
         gathered, in_flight, frame_no, events = [None], [None], [0], []
-        params = pt.RenderParams(W, H, r0, r1, 0, spp, MRR, 1e-4, error, 42)
+        params = pt.RenderParams(W, H, r0, r1, 0, spp, MRR, 1e-4, error, 42, 0, row_stride)
 
         def finish_gather():
             if in_flight[0] is not None:
@@ -558,8 +558,8 @@ def main():
     if not args.no_configs3:
         c3_steps = max(1, min(args.steps, 5))
         c3_elapsed, c3_kms, c3_stats, _, c3_rows = run_frames(scene, C3_W, C3_H, C3_SPP, c3_steps, 1)
-        c3 = {"workload": f"BASELINE configs[3]: Tor.obj {C3_W}x{C3_H} x {C3_SPP} spp, -MRR {MRR}, -ERR -1, {world} row band(s) of "
-                          f"{c3_rows} rows" + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
+        c3 = {"workload": f"BASELINE configs[3]: Tor.obj {C3_W}x{C3_H} x {C3_SPP} spp, -MRR {MRR}, -ERR -1, {world} band(s) of "
+                          f"{c3_rows} rows" + (f" (every {world}th tile row of 8)" if world > 1 else "") + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
               "value": C3_W * C3_H * C3_SPP * c3_steps / c3_elapsed / 1e6, "unit": "Msamples/s", "scaling": "strong",
               "steps": c3_steps, "ms_per_step": c3_elapsed / c3_steps * 1e3,
               "kernel_ms_rank0": sum(c3_kms) / max(len(c3_kms), 1)}
@@ -714,7 +714,7 @@ def main():
             "data": "synthetic (models/Tor.obj, 270 triangles, seed 42, counter RNG)" +
                     (" -- REHEARSAL: all ranks on one GPU, gloo gather; not a scaling measurement" if args.rehearse_on_one_gpu else ""),
             "config": {"workload": f"Tor.obj {W}x{H} x {args.spp} spp, -MRR {MRR}, -ERR -1 (adaptive off), -EPS 1e-4; "
-                                   f"{world} row band(s) of {rows} rows" + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
+                                   f"{world} band(s) of {rows} rows" + (f" (every {world}th tile row of 8)" if world > 1 else "") + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
                        "width": W, "height": H, "spp": args.spp, "max_ray_reflections": MRR, "triangles": n_tri,
                        "parallelism": f"rowband{world}"},
             "roofline": {"bound": "valu_issue", "achieved": v["achieved"], "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",

@@ -1,6 +1,7 @@
-"""The N>1 path on CPU: world_size 2 and 3 with the gloo backend.  Each rank renders its row band (with the oracle,
-since the HIP integrator needs a GPU; the banding, packing, gather and assembly code is the code bench.py runs), rank 0
-gathers once and must obtain exactly the single-process frame: the counter RNG is keyed by the GLOBAL pixel index."""
+"""The N>1 path on CPU: world_size 2 and 3 with the gloo backend.  Each rank renders its band of rows -- every N-th tile row of 8,
+or, for an image with fewer tile rows than ranks, a contiguous band -- (with the oracle, since the HIP integrator needs a GPU; the
+splitting, packing, gather and assembly code is the code bench.py runs), rank 0 gathers once and must obtain exactly the
+single-process frame: the counter RNG is keyed by the GLOBAL pixel index."""
 import importlib
 import os
 import socket
@@ -32,10 +33,20 @@ def _worker(rank, world, port, W, H, spp, mrr, out_path):
     bands = importlib.import_module("path-tracing_amd.bands")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = O.Scene.load(os.path.join(ROOT, "models") + "/", "Tor.obj")
-    r0, r1 = bands.band_rows(H, world, rank)
-    s, s2, c, _ = O.render(sc, W, H, spp, mrr, rows=(r0, r1), threads=2)
+    r0, r1, stride, rows = bands.split(H, world, rank)
+    if stride == 1:
+        s, s2, c, _ = O.render(sc, W, H, spp, mrr, rows=(r0, r1), threads=2)
+    else:   # the oracle renders contiguous rows: one call per tile row of the interleaved band, packed as the device packs them
+        s, s2, c = np.zeros((rows * W, 3), np.float32), np.zeros((rows * W, 3), np.float32), np.zeros(rows * W, np.int32)
+        where = bands.image_rows(H, world, rank)
+        for j in range(rows // 8):
+            t0 = int(where[8 * j])
+            t1 = min(t0 + 8, H)
+            ts, ts2, tc, _ = O.render(sc, W, H, spp, mrr, rows=(t0, t1), threads=2)
+            k = (t1 - t0) * W
+            s[8 * j * W:8 * j * W + k], s2[8 * j * W:8 * j * W + k], c[8 * j * W:8 * j * W + k] = ts, ts2, tc
     band = torch.from_numpy(bands.pack_band(s, s2, c))
-    assert band.numel() == bands.band_floats(W, r1 - r0)
+    assert band.numel() == bands.band_floats(W, rows)
     parts = bands.gather_bands(band, W, H, dist, rank, world)
     if rank == 0:
         fs, fs2, fc = bands.assemble([p.numpy() for p in parts], W, H, world)
@@ -46,7 +57,7 @@ def _worker(rank, world, port, W, H, spp, mrr, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H", [(2, 26), (3, 25)])
+@pytest.mark.parametrize("world,H", [(2, 26), (3, 25), (3, 13)], ids=["2 ranks", "3 ranks", "3 ranks, 2 tile rows: contiguous bands"])
 def test_row_bands_and_single_gather(tmp_path, world, H):
     import oracle_lib as O
     W, spp, mrr = 40, 6, 8
@@ -70,6 +81,18 @@ def test_band_arithmetic():
             assert all(rows[i][1] == rows[i + 1][0] for i in range(n - 1))
             sizes = [b - a for a, b in rows]
             assert max(sizes) - min(sizes) <= 1
+    # the split the ranks really use: every row exactly once, interleaved by tile rows where every rank gets one
+    for H in (1, 7, 8, 9, 25, 50, 1080, 2160, 4320):
+        for n in (1, 2, 3, 4, 8):
+            seen = np.zeros(H, int)
+            for r in range(n):
+                r0, r1, stride, nrows = bands.split(H, n, r)
+                where = bands.image_rows(H, n, r)
+                assert len(where) == nrows and (stride == n if (n > 1 and (H + 7) // 8 >= n) else stride == 1)
+                seen[where[where >= 0]] += 1
+                if stride > 1:
+                    assert r0 == 8 * r and r1 == H and nrows % 8 == 0 and (where[::8] % (8 * n) == 8 * r).all()
+            assert (seen == 1).all(), (H, n)
     assert bands.frame_for(1) == (1920, 1080) and bands.frame_for(2) == (1920, 2160)
     assert bands.frame_for(4) == (3840, 2160) and bands.frame_for(8) == (3840, 4320)
     for n in (1, 2, 4, 8):
