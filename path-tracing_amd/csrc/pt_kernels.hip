@@ -1549,15 +1549,14 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
     // a.blocks_x counts tiles of THIS instantiation's width (the host asks integrator_tile_width)
     // A band is rows [row_begin, row_end) of the image -- or, with row_stride n > 1, every n-th TILE ROW (kTileH image rows) from row_begin
     // on, packed in the band's planes: tile row j of the band is image rows row_begin + j n kTileH ..., plane rows j kTileH ...  (the
-    // interleaved split of a frame over several devices, pt_frame.cpp).  row0 = what to subtract from an image row to get its plane row.
-    const int tile_row = static_cast<int>(tile / a.blocks_x);
-    int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTW, tile_y0 = a.row_begin + tile_row * kTileH * a.row_stride;   // wave-uniform
-    int row0 = a.row_begin + tile_row * kTileH * (a.row_stride - 1);
+    // interleaved split of a frame over several devices, pt_frame.cpp).  acc_y0 = the tile's first row in the band's planes; its first
+    // image row follows from it (and is what the camera ray and the RNG's pixel index take).
+    int tile_x0 = static_cast<int>(tile % a.blocks_x) * kTW, acc_y0 = static_cast<int>(tile / a.blocks_x) * kTileH;   // wave-uniform
     if constexpr (ADAPT != 0) {   // (the division runs on the vector unit: say that its results are scalars, or the 16 x 8 kernel spills one of them)
         tile_x0 = __builtin_amdgcn_readfirstlane(tile_x0);
-        tile_y0 = __builtin_amdgcn_readfirstlane(tile_y0);
-        row0 = __builtin_amdgcn_readfirstlane(row0);
+        acc_y0 = __builtin_amdgcn_readfirstlane(acc_y0);
     }
+    const int tile_y0 = a.row_begin + acc_y0 * a.row_stride;
     // pixel k of the lane: column (lane % 8) + 8 k of the tile, row lane / 8; its slot in the wave's LDS arrays is lane + 64 k
     int x[R];
     const int y = tile_y0 + (lane / kTileW);
@@ -1584,7 +1583,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (in_image[k]) {
-            const size_t p = static_cast<size_t>(y - row0) * a.width + x[k];
+            const size_t p = static_cast<size_t>(acc_y0 + lane / kTileW) * a.width + x[k];
             const int id = lane + 64 * k;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -1613,7 +1612,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
             // (the answers of this instantiation live in LDS, by pixel: below)
         } else if constexpr (!kAccInLds) {
             if (in_image[k] && a.error >= 0.0f) {   // (adaptive sampling off: nobody asks, and a work item need not read its tile at all)
-                const size_t p = static_cast<size_t>(y - row0) * a.width + x[k];
+                const size_t p = static_cast<size_t>(acc_y0 + lane / kTileW) * a.width + x[k];
                 lowvar[k] = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
             }
         } else {
@@ -1635,7 +1634,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
             const uint32_t j = static_cast<uint32_t>(lane) + 64u * kb;
             bool low = false;
             if (tile_x_of(j) < a.width && y < a.row_end) {
-                const size_t p = static_cast<size_t>(y - row0) * a.width + tile_x_of(j);
+                const size_t p = static_cast<size_t>(acc_y0 + lane / kTileW) * a.width + tile_x_of(j);
                 low = low_variance(a.sum[3 * p], a.sum[3 * p + 1], a.sum[3 * p + 2], a.sum2[3 * p], a.sum2[3 * p + 1], a.sum2[3 * p + 2], a.count[p]);
             }
             lds.low.v[j] = static_cast<uint16_t>((static_cast<uint32_t>(pass_first) << 1) | (low ? 1u : 0u));
@@ -1656,7 +1655,7 @@ __global__ __launch_bounds__(kBlock, (integrator_waves<SKY, BIG, STATS, ENV, NAR
                 le = j & 63u;
                 kb = static_cast<int>(j >> 6);
             }
-            const size_t p = static_cast<size_t>(tile_y0 + static_cast<int>(le / kTileW) - row0) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * kb);
+            const size_t p = static_cast<size_t>(acc_y0 + static_cast<int>(le / kTileW)) * a.width + (tile_x0 + static_cast<int>(le % kTileW) + kTileW * kb);
             n0 = a.sum[3 * p] + cr; n1 = a.sum[3 * p + 1] + cg; n2 = a.sum[3 * p + 2] + cb;
             p0 = a.sum2[3 * p] + cr * cr; p1 = a.sum2[3 * p + 1] + cg * cg; p2 = a.sum2[3 * p + 2] + cb * cb;
             nn = a.count[p] + 1;
