@@ -81,7 +81,7 @@ def main():
     shutil.copy(os.path.join(G, "pmc_hbm.json"), os.path.join(P, f"{t}_pmc_hbm.json"))
     if os.path.exists(os.path.join(G, "pmc_hbm_c2_pmc_hbm.json")):      # BASELINE configs[2]: the counters of the 1024-spp launch
         shutil.copy(os.path.join(G, "pmc_hbm_c2_pmc_hbm.json"), os.path.join(P, f"{t}_c2_pmc_hbm.json"))
-    for name in ("open_scene_probe.jsonl", "t_sweep.jsonl"):
+    for name in ("open_scene_probe.jsonl", "t_sweep.jsonl", "band_balance.jsonl"):
         if os.path.exists(os.path.join(G, name)) and os.path.getsize(os.path.join(G, name)) > 0:
             shutil.copy(os.path.join(G, name), os.path.join(P, f"{t}_{name}"))
     sky = glob.glob(os.path.join(G, "kt_sky", "**", "*kernel_stats.csv"), recursive=True)

@@ -6,6 +6,7 @@
 #   kt/                  rocprofv3 --kernel-trace --stats of the same command (no PMC in that run, CPU leg skipped)
 #   configs.jsonl        every BASELINE configuration on one GPU (tools/run_configs.py)
 #   mutation_sweep.jsonl tools/mutation_sweep.py
+#   band_balance.jsonl   tools/band_balance_probe.py (kernel time of every band of the multi-device splits, on one GPU)
 #   pmc_tor/ pmc_x64/ pmc_sky/   detailed SQ / TCP counter passes (one group per pass, never with a trace domain)
 #   phase_*.log          per-phase shader-clock shares from the diagnostic build (libpt_phase.so)
 #   blockprof_*          execution counters of the instrumented code object (libpt_blockprof.so + lib/blockprof/pt_bp.hsaco)
@@ -43,6 +44,8 @@ rocprofv3 --kernel-trace --stats -d "$O/kt_sky" -o kt --output-format csv -- "$P
 # the open-scene probe (live rays per wave-segment by -MRR) and the triangle-count sweep across the small / big switch
 python3 "$R/tools/open_scene_probe.py" --spp 64 > "$O/open_scene_probe.jsonl" 2> "$O/open_scene_probe.err"
 python3 "$R/tools/t_sweep.py" > "$O/t_sweep.jsonl" 2> "$O/t_sweep.err"
+# what every device of a 2 / 4 / 8-device node would have to render: contiguous row bands against the interleaved split, band by band on this GPU
+python3 "$R/tools/band_balance_probe.py" 2> "$O/band_balance.err" | grep frame > "$O/band_balance.jsonl"
 echo "pmc detail done"
 PT_HIP_LIB=$R/path-tracing_amd/lib/libpt_phase.so python3 "$R/tools/tor_probe.py" > "$O/phase_tor.log" 2>&1
 PT_HIP_LIB=$R/path-tracing_amd/lib/libpt_phase.so python3 "$R/tools/c5_probe.py" 64,195 > "$O/phase_x64_x195.log" 2>&1
