@@ -104,6 +104,8 @@ struct FrameXfer {
     size_t tile_row_bytes = 0;        // 8 rows of the plane
     size_t full_tile_rows = 0;        // tile rows copied whole
     size_t tail_bytes = 0;            // rows of the band's last tile row that lie inside the image (0: it is whole too)
+    bool staged = false;              // the band is on another device: its plane arrives in the root's staging buffer first
+    size_t stage_offset = 0;          // ... at this offset (floats)
 };
 
 struct pt_frame {
@@ -237,9 +239,10 @@ int frame_create_impl(const pt_scene *scene, const int32_t *devices, int32_t n_b
                     x.tile_row_bytes = 8u * static_cast<size_t>(width) * elem;
                     x.full_tile_rows = partial ? count - 1 : count;
                     x.tail_bytes = partial ? last_rows * static_cast<size_t>(width) * elem : 0;
-                    x.dst = nullptr;                         // set below for staged bands
+                    x.dst = nullptr;                         // staged bands: set once the staging buffer exists
+                    x.staged = staged;
                     if (staged) {
-                        x.dst = reinterpret_cast<void *>(staging_floats + 1);    // (offset + 1 until the buffer exists)
+                        x.stage_offset = staging_floats;
                         staging_floats += (x.words + 63) / 64 * 64;
                     }
                 }
@@ -251,7 +254,7 @@ int frame_create_impl(const pt_scene *scene, const int32_t *devices, int32_t n_b
         if (staging_floats > 0) {
             PT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&f->d_staging), staging_floats * sizeof(float)));
             for (FrameXfer &x : f->xfers)
-                if (x.dst) x.dst = f->d_staging + (reinterpret_cast<size_t>(x.dst) - 1);
+                if (x.staged) x.dst = f->d_staging + x.stage_offset;
         }
         if (!f->gather_stream) PT_HIP_TRY(hipStreamCreateWithFlags(&f->gather_stream, hipStreamNonBlocking));   // staged bands are put in place on it
     }
