@@ -716,7 +716,7 @@ def main():
             "config": {"workload": f"Tor.obj {W}x{H} x {args.spp} spp, -MRR {MRR}, -ERR -1 (adaptive off), -EPS 1e-4; "
                                    f"{world} band(s) of {rows} rows" + (f" (every {world}th tile row of 8)" if world > 1 else "") + (", one RCCL gather of 28 B/pixel to rank 0" if world > 1 else ""),
                        "width": W, "height": H, "spp": args.spp, "max_ray_reflections": MRR, "triangles": n_tri,
-                       "parallelism": f"rowband{world}"},
+                       "parallelism": f"rowband{world}" if world == 1 else f"tilerows_interleaved{world}"},
             "roofline": {"bound": "valu_issue", "achieved": v["achieved"], "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": v["frac"],
                          "traffic": traffic,

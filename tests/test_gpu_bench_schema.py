@@ -124,7 +124,7 @@ def test_self_launch_two_ranks_and_too_many_gpus(tmp_path):
                         "--rehearse-on-one-gpu", "--no-configs3"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["config"]["parallelism"] == "rowband2"
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["config"]["parallelism"] == "tilerows_interleaved2"
     cx = j["cxx_frame"]["weak"]       # the C++ host's two-band frame next to the two-rank torch leg (rehearsed: device copies)
     assert cx["bands"] == 2 and cx["transport"] == "device_copies" and cx["value"] > 100.0
     # the diagnosis a first multi-device run should leave behind: every band's / rank's kernel time and the gather alone
