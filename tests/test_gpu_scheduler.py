@@ -19,11 +19,11 @@ pt = importlib.import_module("path-tracing_amd")
 pytestmark = pytest.mark.gpu
 
 
-def _render(L, d, name, W, H, rows, slices, mrr, error, seed, sky=None):
+def _render(L, d, name, W, H, rows, slices, mrr, error, seed, sky=None, stride=0):
     sc = pt.Scene.load_obj(d, name, device=0, library=L)
     if sky:
         sc.set_skybox(sky)
-    ses = pt.Session(sc, W, H, rows=rows)
+    ses = pt.Session(sc, W, H, rows=rows, row_stride=stride)
     at = 0
     for n in slices:
         ses.render(at, n, mrr, error=error, seed=seed)
@@ -56,6 +56,10 @@ def test_random_launches_against_the_plainest_configuration(tmp_path, case):
     H = int(rng.integers(280, 1300))
     r0 = int(rng.integers(0, H // 3)) if case % 3 == 0 else 0
     r1 = int(rng.integers(2 * H // 3, H + 1)) if case % 3 == 0 else H
+    stride = 0
+    if case % 4 == 3:      # an interleaved band: every n-th tile row from tile row k on, against those rows of the plain frame
+        stride = int(rng.integers(2, 10))
+        r0, r1 = 8 * int(rng.integers(0, min(stride, (H + 7) // 8))), H
     spp = int(rng.integers(12, 70)) if kind != "x9" else int(rng.integers(12, 36))
     cut = int(rng.integers(1, spp))
     error = float(rng.choice([-1.0, 0.001, 0.001, 0.02, 0.3]))
@@ -63,14 +67,19 @@ def test_random_launches_against_the_plainest_configuration(tmp_path, case):
     seed = int(rng.integers(1, 1000))
     try:
         L.pt_test_set_mutation(b"reset", 0.0)
-        mine = _render(L, dd, name, W, H, (r0, r1), (cut, spp - cut), mrr, error, seed, sky)
+        mine = _render(L, dd, name, W, H, (r0, r1), (cut, spp - cut), mrr, error, seed, sky, stride)
         L.pt_test_set_mutation(b"tile_width", 1.0)
         L.pt_test_set_mutation(b"items_per_slot", -1.0)
         L.pt_test_set_mutation(b"chunk_min", 8.0)
-        plain = _render(L, dd, name, W, H, (r0, r1), (spp,), mrr, error, seed, sky)
+        plain = _render(L, dd, name, W, H, (r0, r1) if not stride else (0, H), (spp,), mrr, error, seed, sky)
     finally:
         L.pt_test_set_mutation(b"reset", 0.0)
-    what = (kind, W, H, (r0, r1), spp, cut, error, mrr, seed)
+    what = (kind, W, H, (r0, r1), stride, spp, cut, error, mrr, seed)
+    if stride:
+        where = pt.interleaved_rows(H, r0, stride)
+        inside = where >= 0
+        mine = tuple(a.reshape(len(where), W, -1)[inside].reshape(-1, a.shape[-1] if a.ndim > 1 else 1).squeeze() for a in mine)
+        plain = tuple(a.reshape(H, W, -1)[where[inside]].reshape(-1, a.shape[-1] if a.ndim > 1 else 1).squeeze() for a in plain)
     assert plain[2].sum() > 0, what
     assert np.array_equal(mine[2], plain[2]), what
     assert np.array_equal(mine[0].view(np.uint32), plain[0].view(np.uint32)) and np.array_equal(mine[1].view(np.uint32), plain[1].view(np.uint32)), what
