@@ -1,7 +1,7 @@
 """The host-side choices of a launch -- which instantiation (8 x 8, 16 x 8, 32 x 8 tiles; plain passes or batches of adaptive sampling),
 how the pass range is cut into chunks (3/4 of the rest down to single passes, or equal chunks between one and two tiles per wave slot)
--- must not change a bit of the frame.  Random launches: frame size, row band, pass count cut into two slices on a device-resident
-session, adaptive threshold, scene class; the library's own choices against the plainest configuration the test hooks can pin
+-- must not change a bit of the frame.  Random launches: frame size, row band (one in four: an interleaved band, every n-th tile row,
+against those rows of the whole frame), pass count cut into two slices on a device-resident session, adaptive threshold, scene class; the library's own choices against the plainest configuration the test hooks can pin
 (8 x 8 tiles, pixels sit passes out, 3/4 chunks with the old floor of 8 passes).  GPU against GPU: the oracle's bits are what
 tests/test_gpu_parity.py and tests/test_gpu_configs.py compare with on small frames, this test carries them to full-size launches."""
 import importlib
